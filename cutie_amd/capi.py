@@ -1,0 +1,127 @@
+"""ctypes binding of libcutie_hip.so (the C ABI declared in include/cutie_hip.h).
+
+PyTorch-ROCm supplies device memory and streams only; every entry point takes raw device
+pointers and the current HIP stream.  There is no CPU fallback: if the library is missing or
+an entry point fails, a CutieError is raised.
+"""
+import ctypes
+import os
+
+import torch
+
+F32, BF16 = 0, 1
+MAX_SEGS = 6
+REDUCE_SCRATCH = 1024
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libcutie_hip.so")
+
+
+class CutieError(RuntimeError):
+    pass
+
+
+class ConvSeg(ctypes.Structure):
+    _fields_ = [("x", ctypes.c_void_p), ("w", ctypes.c_void_p), ("w_tap_stride", ctypes.c_int64),
+                ("ld_x", ctypes.c_int), ("cin", ctypes.c_int), ("kh", ctypes.c_int), ("kw", ctypes.c_int),
+                ("dil", ctypes.c_int), ("flip", ctypes.c_int)]
+
+
+_c = ctypes
+_vp, _i, _i64, _f, _sz = _c.c_void_p, _c.c_int, _c.c_int64, _c.c_float, _c.c_size_t
+
+# name -> (restype, argtypes); must list every symbol of include/cutie_hip.h
+SIGNATURES = {
+    "cutie_version": (_i, []),
+    "cutie_last_error": (_c.c_char_p, []),
+    "cutie_grid_build_workspace_bytes": (_sz, [_i]),
+    "cutie_grid_build": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
+                              _vp, _sz, _vp]),
+    "cutie_embed_fwd": (_i, [_vp, _i64, _vp, _i, _i, _vp, _i, _i, _vp, _vp]),
+    "cutie_embed_bwd": (_i, [_vp, _i64, _vp, _i, _i, _vp, _i, _i, _vp]),
+    "cutie_conv_fwd": (_i, [_c.POINTER(ConvSeg), _i, _i, _i, _i, _i, _vp, _i, _i, _vp, _i, _vp, _i, _vp]),
+    "cutie_conv_wgrad_workspace_bytes": (_sz, [_i, _i, _i, _i, _i, _i, _i]),
+    "cutie_conv_wgrad": (_i, [_vp, _i, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _i, _i, _vp, _sz, _vp]),
+    "cutie_pack_weights": (_i, [_vp, _i, _i, _i, _vp, _i, _vp, _i, _i, _vp]),
+    "cutie_in_stats": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp]),
+    "cutie_in_apply": (_i, [_vp, _i, _i, _vp, _f, _vp, _i, _i, _i, _i, _i, _vp]),
+    "cutie_in_bwd_stats": (_i, [_vp, _i, _i, _vp, _i, _i, _vp, _f, _vp, _i, _i, _i, _vp]),
+    "cutie_in_bwd_apply": (_i, [_vp, _i, _i, _vp, _i, _i, _vp, _f, _vp, _i, _vp, _i, _i, _vp, _i, _i, _i, _vp]),
+    "cutie_spatial_mean_bcast": (_i, [_vp, _i, _i, _vp, _i, _i, _i, _i, _i, _vp]),
+    "cutie_softmax_ce_fwd": (_i, [_vp, _i, _i, _vp, _i64, _i, _vp, _vp, _vp, _vp]),
+    "cutie_hnm_workspace_bytes": (_sz, [_i64]),
+    "cutie_hnm_weights": (_i, [_vp, _vp, _i64, _i, _vp, _vp, _vp, _sz, _vp]),
+    "cutie_softmax_ce_bwd": (_i, [_vp, _vp, _vp, _i64, _i, _vp, _i, _i, _vp]),
+    "cutie_l2_add": (_i, [_vp, _vp, _i64, _f, _vp, _vp, _vp]),
+    "cutie_sumsq": (_i, [_vp, _i64, _i, _vp, _vp, _vp]),
+    "cutie_adam_step": (_i, [_vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _vp, _f, _f, _vp]),
+    "cutie_batch_gather": (_i, [_vp, _i, _i, _vp, _i, _i, _i, _vp, _i, _i, _vp]),
+    "cutie_convert": (_i, [_vp, _i, _i, _vp, _i, _i, _i64, _i, _vp]),
+}
+
+_lib = None
+
+
+def lib():
+    """The loaded library; raises CutieError (never falls back) when it is absent."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise CutieError("%s is missing: build it with `python -m cutie_amd.build` (hipcc, gfx950). "
+                             "There is no CPU fallback." % LIB_PATH)
+        try:
+            handle = ctypes.CDLL(LIB_PATH)
+        except OSError as e:
+            raise CutieError("cannot load %s: %s" % (LIB_PATH, e))
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(handle, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = handle
+    return _lib
+
+
+def _check(rc, name):
+    if rc != 0:
+        msg = lib().cutie_last_error()
+        raise CutieError("%s failed (%d): %s" % (name, rc, msg.decode() if msg else "?"))
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def dt_of(t):
+    if t.dtype == torch.float32:
+        return F32
+    if t.dtype == torch.bfloat16:
+        return BF16
+    raise CutieError("unsupported activation dtype %s" % t.dtype)
+
+
+def torch_dtype(dt):
+    return torch.float32 if dt == F32 else torch.bfloat16
+
+
+def ptr(t):
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise CutieError("expected a device tensor")
+    return t.data_ptr()
+
+
+def ld_of(t):
+    """leading dimension (elements) of a [..., C] view whose rows are dense in the last axis
+    and whose leading axes collapse to one row index"""
+    if t.stride(-1) != 1:
+        raise CutieError("channel axis must be contiguous")
+    ld = t.stride(-2)
+    for d in range(t.dim() - 2):
+        if t.stride(d) != t.stride(d + 1) * t.shape[d + 1]:
+            raise CutieError("view is not row-collapsible: shape %s strides %s" % (tuple(t.shape), t.stride()))
+    return ld
+
+
+def call(name, *args):
+    _check(getattr(lib(), name)(*args), name)

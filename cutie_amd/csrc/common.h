@@ -1,0 +1,89 @@
+// Shared helpers for the gfx950 kernels (error reporting, dtype load/store, wave reductions).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+
+#include "../../include/cutie_hip.h"
+
+namespace cutie {
+
+void set_error(const char* fmt, ...);
+
+#define CUTIE_CHECK_ARG(cond, ...)                     \
+    do {                                               \
+        if (!(cond)) {                                 \
+            cutie::set_error(__VA_ARGS__);             \
+            return CUTIE_E_ARG;                        \
+        }                                              \
+    } while (0)
+
+#define CUTIE_CHECK_HIP(expr)                                                          \
+    do {                                                                               \
+        hipError_t e__ = (expr);                                                       \
+        if (e__ != hipSuccess) {                                                       \
+            cutie::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e__),   \
+                             __FILE__, __LINE__);                                      \
+            return CUTIE_E_HIP;                                                        \
+        }                                                                              \
+    } while (0)
+
+#define CUTIE_CHECK_LAUNCH() CUTIE_CHECK_HIP(hipGetLastError())
+
+static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+static inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+typedef unsigned short bf16_t;  // raw bits
+
+// round-to-nearest-even f32 -> bf16 (NaN stays NaN): lowers to v_cvt_pk_bf16_f32 on gfx950
+__device__ __forceinline__ bf16_t f2bf(float f) {
+    return __builtin_bit_cast(bf16_t, static_cast<__bf16>(f));
+}
+__device__ __forceinline__ float bf2f(bf16_t b) {
+    return __uint_as_float(static_cast<unsigned>(b) << 16);
+}
+
+template <int DT> struct elem;
+template <> struct elem<CUTIE_F32> { typedef float type; };
+template <> struct elem<CUTIE_BF16> { typedef bf16_t type; };
+
+__device__ __forceinline__ float load_as_f32(const float* p) { return *p; }
+__device__ __forceinline__ float load_as_f32(const bf16_t* p) { return bf2f(*p); }
+__device__ __forceinline__ void store_from_f32(float* p, float v) { *p = v; }
+__device__ __forceinline__ void store_from_f32(bf16_t* p, float v) { *p = f2bf(v); }
+
+// 4 consecutive elements <-> float4 (16 B for f32, 8 B for bf16); pointers must be aligned
+__device__ __forceinline__ float4 load4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ float4 load4(const bf16_t* p) {
+    uint2 u = *reinterpret_cast<const uint2*>(p);
+    float4 r;
+    r.x = __uint_as_float(u.x << 16);
+    r.y = __uint_as_float(u.x & 0xffff0000u);
+    r.z = __uint_as_float(u.y << 16);
+    r.w = __uint_as_float(u.y & 0xffff0000u);
+    return r;
+}
+__device__ __forceinline__ void store4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+__device__ __forceinline__ void store4(bf16_t* p, float4 v) {
+    uint2 u;
+    u.x = static_cast<unsigned>(f2bf(v.x)) | (static_cast<unsigned>(f2bf(v.y)) << 16);
+    u.y = static_cast<unsigned>(f2bf(v.z)) | (static_cast<unsigned>(f2bf(v.w)) << 16);
+    *reinterpret_cast<uint2*>(p) = u;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// runtime dtype dispatch over one or two activation dtypes
+#define CUTIE_DISPATCH_DTYPE(dt, NAME, ...)                              \
+    switch (dt) {                                                        \
+        case CUTIE_F32: { constexpr int NAME = CUTIE_F32; __VA_ARGS__; break; }   \
+        case CUTIE_BF16: { constexpr int NAME = CUTIE_BF16; __VA_ARGS__; break; } \
+        default: cutie::set_error("unknown dtype %d", (int)(dt)); return CUTIE_E_ARG; \
+    }
+
+}  // namespace cutie

@@ -1,0 +1,557 @@
+// K2-K5: stride-1 SAME (dilated) convolution as an implicit GEMM on the gfx950 matrix cores.
+//
+// Replaces tf.nn.conv2d / tf.nn.atrous_conv2d (+ bias_add + relu) of
+// /root/reference/model_framework.py:168-204,414-422 and the two gradients tf.gradients
+// derives for them (data gradient = the same kernel with negated tap shifts and [tap][cin][cout]
+// weights; weight gradient = conv_wgrad below).
+//
+// Forward / data-gradient kernel (conv_kernel)
+//   GEMM view: M = output pixels, N = output channels, K = taps x input channels.
+//   Workgroup = 256 lanes = 4 waves (2 x 2); tile = 128 pixels x 128 channels; a wave owns
+//   64 x 64 = 4 x 4 MFMA 16x16 accumulators.  The 128 pixels are TH rows x (TWB*16) columns
+//   of ONE sample, so a whole input row patch (with its +-2*dil column halo, zero filled
+//   outside the image) is staged in LDS once per (tap row, 128-byte channel chunk) and reused
+//   by all kw column taps: the A operand costs 1/kw of a plain GEMM's staging traffic.
+//   16-pixel MFMA row blocks whose shifted input lies wholly outside the image are skipped
+//   (wave-uniform), which is where the in-bounds FLOP count of SURVEY.md 8(d) comes from.
+//   LDS images hold 128 B per pixel / per weight row; the 16-byte chunk index is XOR-swizzled
+//   with (row >> 1) & 7 so that ds_read_b128 fragment reads spread over the 64 banks.
+//   bf16: v_mfma_f32_16x16x32_bf16;  f32 (parity mode): 4 x v_mfma_f32_16x16x4_f32 on the same
+//   16-byte fragments (exact f32 FMA chains).
+//   Epilogue: + bias, ReLU, per-(sample, channel) sum / sum-of-squares for the instance norm
+//   (wave shuffle reduce + one f32 atomic per wave and channel), tile staged through LDS and
+//   written as whole 16-byte row pieces into the (possibly wider) destination buffer.
+//
+// Weight-gradient kernel (wgrad_kernel)
+//   GEMM view per tap: M = cin, N = cout, K = pixels.  Both operands are pixel-major in HBM,
+//   i.e. K-major, so the bf16 fragments come from ds_read_b64_tr_b16 (hardware transposed
+//   read) out of row-major [pixel][channel] LDS images; f32 uses plain ds_read_b32.
+//   K is split over row groups into f32 slabs, summed by wgrad_reduce_kernel in a fixed order
+//   (deterministic, no float atomics).
+#include "common.h"
+
+namespace {
+using namespace cutie;
+
+typedef __attribute__((ext_vector_type(8))) short short8_t;
+typedef __attribute__((ext_vector_type(4))) short short4_t;
+typedef __attribute__((ext_vector_type(4))) float float4_t;
+
+struct Seg {
+    const char* x;
+    const char* w;
+    long long w_tap_stride;  // elements
+    int ld_x, cin, kh, kw, dil, sgn;
+};
+
+struct ConvParams {
+    Seg seg[CUTIE_MAX_SEGS];
+    int nseg;
+    int B, H, W, n_out;
+    char* out;
+    int ld_out;
+    const float* bias;
+    int relu;
+    float* stats;
+    int TH, TWB, tiles_h, tiles_w, n_tiles_n;
+    int a_bytes;  // LDS bytes reserved for the A patch
+};
+
+template <int DT> struct Traits;
+template <> struct Traits<CUTIE_BF16> { static constexpr int ES = 2; static constexpr int BKE = 64; };
+template <> struct Traits<CUTIE_F32> { static constexpr int ES = 4; static constexpr int BKE = 32; };
+
+__device__ __forceinline__ int swz(int row) { return (row >> 1) & 7; }
+
+template <int DT>
+__device__ __forceinline__ void mma_frag(const uint4& a, const uint4& b, float4_t& c) {
+    if constexpr (DT == CUTIE_BF16) {
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(short8_t, a), __builtin_bit_cast(short8_t, b), c,
+                                                    0, 0, 0);
+    } else {
+        c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.x), __uint_as_float(b.x), c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.y), __uint_as_float(b.y), c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.z), __uint_as_float(b.z), c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.w), __uint_as_float(b.w), c, 0, 0, 0);
+    }
+}
+
+template <int DT, int ODT>
+__global__ __launch_bounds__(256) void conv_kernel(ConvParams p) {
+    constexpr int ES = Traits<DT>::ES;
+    constexpr int BKE = Traits<DT>::BKE;
+    typedef typename elem<ODT>::type TO;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* As = smem;
+    char* Bs = smem + p.a_bytes;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int li = lane & 15, lg = lane >> 4;
+
+    // workgroup -> (sample, tile row, tile col, channel tile); channel tile fastest
+    int bid = blockIdx.x;
+    const int nt = bid % p.n_tiles_n; bid /= p.n_tiles_n;
+    const int tw = bid % p.tiles_w; bid /= p.tiles_w;
+    const int th = bid % p.tiles_h;
+    const int b = bid / p.tiles_h;
+    const int TW = p.TWB * 16;
+    const int h0 = th * p.TH, w0 = tw * TW, n0 = nt * 128;
+
+    // this wave's four pixel blocks
+    int blk_r[4], blk_c[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        const int mb = wm * 4 + m;
+        blk_r[m] = mb / p.TWB;
+        blk_c[m] = (mb % p.TWB) * 16;
+    }
+
+    float4_t acc[4][4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int n = 0; n < 4; ++n) acc[m][n] = float4_t{0.f, 0.f, 0.f, 0.f};
+
+    for (int s = 0; s < p.nseg; ++s) {
+        const Seg sg = p.seg[s];
+        const int PAD = (sg.kw / 2) * sg.dil;
+        const int PW = TW + 2 * PAD;
+        const int n_chunks_a = p.TH * PW * 8;
+        for (int i = 0; i < sg.kh; ++i) {
+            const int sy = sg.sgn * (i - sg.kh / 2) * sg.dil;
+            // all tile rows outside the image for this tap row -> nothing to add
+            if (h0 + sy + p.TH - 1 < 0 || h0 + sy >= p.H) continue;
+            for (int cc = 0; cc < sg.cin / BKE; ++cc) {
+                __syncthreads();  // previous compute has finished reading As / Bs
+                // ---- stage the input row patch: TH rows x PW columns x 128 B
+                for (int base = 0; base < n_chunks_a; base += 256 * 4) {
+                    uint4 v[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int idx = base + u * 256 + tid;
+                        v[u] = make_uint4(0u, 0u, 0u, 0u);
+                        if (idx < n_chunks_a) {
+                            const int c = idx & 7, pix = idx >> 3;
+                            const int r = pix / PW, pc = pix - r * PW;
+                            const int hin = h0 + r + sy, win = w0 + pc - PAD;
+                            if (hin >= 0 && hin < p.H && win >= 0 && win < p.W) {
+                                const long long off =
+                                    ((long long)(b * p.H + hin) * p.W + win) * sg.ld_x + (long long)cc * BKE;
+                                v[u] = *reinterpret_cast<const uint4*>(sg.x + off * ES + c * 16);
+                            }
+                        }
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int idx = base + u * 256 + tid;
+                        if (idx < n_chunks_a) {
+                            const int c = idx & 7, pix = idx >> 3;
+                            const int pc = pix % PW;
+                            *reinterpret_cast<uint4*>(As + (pix * 8 + (c ^ swz(pc))) * 16) = v[u];
+                        }
+                    }
+                }
+                for (int j = 0; j < sg.kw; ++j) {
+                    const int sx = sg.sgn * (j - sg.kw / 2) * sg.dil;
+                    if (j > 0) __syncthreads();  // previous tap has finished reading Bs
+                    // ---- stage the weight tile: 128 rows x 128 B
+                    {
+                        const char* wt = sg.w + ((long long)(i * sg.kw + j) * sg.w_tap_stride) * ES;
+                        uint4 v[4];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            const int idx = u * 256 + tid;
+                            const int c = idx & 7, n = idx >> 3;
+                            v[u] = make_uint4(0u, 0u, 0u, 0u);
+                            if (n0 + n < p.n_out) {
+                                const long long off = (long long)(n0 + n) * sg.cin + (long long)cc * BKE;
+                                v[u] = *reinterpret_cast<const uint4*>(wt + off * ES + c * 16);
+                            }
+                        }
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            const int idx = u * 256 + tid;
+                            const int c = idx & 7, n = idx >> 3;
+                            *reinterpret_cast<uint4*>(Bs + (n * 8 + (c ^ swz(n))) * 16) = v[u];
+                        }
+                    }
+                    __syncthreads();
+                    // ---- 2 x (4 + 4 fragment reads, 16 MFMA)
+                    bool live[4];
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) {
+                        const int h = h0 + blk_r[m], wc = w0 + blk_c[m];
+                        live[m] = h < p.H && wc < p.W && h + sy >= 0 && h + sy < p.H && wc + sx + 15 >= 0 &&
+                                  wc + sx < p.W;
+                    }
+#pragma unroll
+                    for (int kk = 0; kk < 2; ++kk) {
+                        uint4 bf[4];
+#pragma unroll
+                        for (int n = 0; n < 4; ++n) {
+                            const int nl = wn * 64 + n * 16 + li;
+                            bf[n] = *reinterpret_cast<const uint4*>(Bs + (nl * 8 + ((kk * 4 + lg) ^ swz(nl))) * 16);
+                        }
+#pragma unroll
+                        for (int m = 0; m < 4; ++m) {
+                            if (!live[m]) continue;
+                            const int pc = PAD + blk_c[m] + sx + li;
+                            const int pix = blk_r[m] * PW + pc;
+                            const uint4 af =
+                                *reinterpret_cast<const uint4*>(As + (pix * 8 + ((kk * 4 + lg) ^ swz(pc))) * 16);
+#pragma unroll
+                            for (int n = 0; n < 4; ++n) mma_frag<DT>(af, bf[n], acc[m][n]);
+                        }
+                    }
+                }
+            }
+        }
+    }
+
+    // ---- epilogue: bias, ReLU, instance-norm moments, LDS-staged coalesced store
+    __syncthreads();
+    TO* Cs = reinterpret_cast<TO*>(smem);  // [128 pixels][128 channels]
+    float ssum[4], ssq[4];
+#pragma unroll
+    for (int n = 0; n < 4; ++n) {
+        const int col = n0 + wn * 64 + n * 16 + li;
+        const float bv = (p.bias && col < p.n_out) ? p.bias[col] : 0.f;
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            const int h = h0 + blk_r[m];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int w = w0 + blk_c[m] + lg * 4 + r;
+                float v = acc[m][n][r] + bv;
+                if (p.relu) v = fmaxf(v, 0.f);
+                if (!(h < p.H && w < p.W)) v = 0.f;
+                s1 += v;
+                s2 += v * v;
+                const int ml = (wm * 4 + m) * 16 + lg * 4 + r;
+                store_from_f32(Cs + ml * 128 + wn * 64 + n * 16 + li, v);
+            }
+        }
+        ssum[n] = s1;
+        ssq[n] = s2;
+    }
+    if (p.stats) {
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+            float s1 = ssum[n], s2 = ssq[n];
+            s1 += __shfl_xor(s1, 16, 64); s1 += __shfl_xor(s1, 32, 64);
+            s2 += __shfl_xor(s2, 16, 64); s2 += __shfl_xor(s2, 32, 64);
+            const int col = n0 + wn * 64 + n * 16 + li;
+            if (lg == 0 && col < p.n_out) {
+                atomicAdd(p.stats + ((long long)b * p.n_out + col) * 2 + 0, s1);
+                atomicAdd(p.stats + ((long long)b * p.n_out + col) * 2 + 1, s2);
+            }
+        }
+    }
+    __syncthreads();
+    constexpr int EPC = 16 / sizeof(TO);         // elements per 16-byte piece
+    constexpr int PIECES = 128 / EPC;            // pieces per pixel row of the tile
+    for (int idx = tid; idx < 128 * PIECES; idx += 256) {
+        const int ml = idx / PIECES, pc = idx - ml * PIECES;
+        const int mb = ml >> 4;
+        const int h = h0 + mb / p.TWB, w = w0 + (mb % p.TWB) * 16 + (ml & 15);
+        const int col = n0 + pc * EPC;
+        if (h < p.H && w < p.W && col < p.n_out) {
+            TO* dst = reinterpret_cast<TO*>(p.out) + ((long long)(b * p.H + h) * p.W + w) * p.ld_out + col;
+            const TO* src = Cs + ml * 128 + pc * EPC;
+            if (col + EPC <= p.n_out && ((reinterpret_cast<uintptr_t>(dst) & 15) == 0)) {
+                *reinterpret_cast<uint4*>(dst) = *reinterpret_cast<const uint4*>(src);
+            } else {
+                for (int e = 0; e < EPC && col + e < p.n_out; ++e) dst[e] = src[e];
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+struct WgradParams {
+    const char* x;
+    const char* dz;
+    int ld_x, cin, ld_dz, cout;
+    int B, H, W, kh, kw, dil;
+    float* slabs;    // [splits][taps][cin][cout]
+    int splits, mt, ntile;
+};
+
+__device__ __forceinline__ int tr_func(int r) { return (r & 3) | (((r >> 3) & 1) << 2); }
+
+template <int DT>
+__global__ __launch_bounds__(256) void wgrad_kernel(WgradParams p) {
+    constexpr int ES = Traits<DT>::ES;
+    constexpr int ROWB = 128 * ES;  // bytes per staged pixel row (128 channels)
+    constexpr int KPIX = 64;        // pixels per stage
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* Xs = smem;
+    char* Ds = smem + KPIX * ROWB;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int li = lane & 15, lg = lane >> 4;
+
+    int bid = blockIdx.x;
+    const int nt = bid % p.ntile; bid /= p.ntile;
+    const int mt = bid % p.mt;
+    const int tap = bid / p.mt;
+    const int ti = tap / p.kw, tj = tap - ti * p.kw;
+    const int sy = (ti - p.kh / 2) * p.dil, sx = (tj - p.kw / 2) * p.dil;
+    const int m0 = mt * 128, n0 = nt * 128;
+
+    const int rows_total = p.B * p.H;
+    const int per = (rows_total + p.splits - 1) / p.splits;
+    const int row_begin = blockIdx.y * per;
+    const int row_end = min(rows_total, row_begin + per);
+
+    float4_t acc[4][4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int n = 0; n < 4; ++n) acc[m][n] = float4_t{0.f, 0.f, 0.f, 0.f};
+
+    constexpr int CPR = ROWB / 16;  // 16-byte chunks per staged row: 16 (bf16) / 32 (f32)
+    constexpr int EPC = 16 / ES;    // elements per chunk
+    for (int row = row_begin; row < row_end; ++row) {
+        const int b = row / p.H, h = row - b * p.H;
+        const int hh = h + sy;
+        if (hh < 0 || hh >= p.H) continue;
+        for (int ws = 0; ws < p.W; ws += KPIX) {
+            if (ws + sx + KPIX <= 0 || ws + sx >= p.W) continue;  // whole x window outside: zeros
+            __syncthreads();
+#pragma unroll
+            for (int u = 0; u < (KPIX * CPR) / 256; ++u) {
+                const int idx = u * 256 + tid;
+                const int c = idx % CPR, r = idx / CPR;
+                const int w = ws + r;
+                uint4 vx = make_uint4(0u, 0u, 0u, 0u), vd = vx;
+                const int wsrc = w + sx;
+                if (w < p.W && wsrc >= 0 && wsrc < p.W && m0 + c * EPC < p.cin) {
+                    const long long off = ((long long)(b * p.H + hh) * p.W + wsrc) * p.ld_x + m0 + c * EPC;
+                    vx = *reinterpret_cast<const uint4*>(p.x + off * ES);
+                }
+                if (w < p.W && n0 + c * EPC < p.cout) {
+                    const long long off = ((long long)(b * p.H + h) * p.W + w) * p.ld_dz + n0 + c * EPC;
+                    vd = *reinterpret_cast<const uint4*>(p.dz + off * ES);
+                }
+                int dst;
+                if constexpr (DT == CUTIE_BF16) {
+                    dst = r * ROWB + (((c >> 1) ^ tr_func(r)) * 32) + (c & 1) * 16;
+                } else {
+                    dst = r * ROWB + c * 16;
+                }
+                *reinterpret_cast<uint4*>(Xs + dst) = vx;
+                *reinterpret_cast<uint4*>(Ds + dst) = vd;
+            }
+            __syncthreads();
+            if constexpr (DT == CUTIE_BF16) {
+#pragma unroll
+                for (int ks = 0; ks < KPIX / 32; ++ks) {
+                    const int q = li >> 2, pp = li & 3;
+                    const int r1 = ks * 32 + lg * 8 + q, r2 = r1 + 4;
+                    short8_t af[4], bf[4];
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) {
+                        const int blk = wm * 4 + m;
+                        const short4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                            (__attribute__((address_space(3))) short4_t*)(Xs + r1 * ROWB + ((blk ^ tr_func(r1)) * 32) + pp * 8));
+                        const short4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                            (__attribute__((address_space(3))) short4_t*)(Xs + r2 * ROWB + ((blk ^ tr_func(r2)) * 32) + pp * 8));
+                        af[m] = short8_t{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                    }
+#pragma unroll
+                    for (int n = 0; n < 4; ++n) {
+                        const int blk = wn * 4 + n;
+                        const short4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                            (__attribute__((address_space(3))) short4_t*)(Ds + r1 * ROWB + ((blk ^ tr_func(r1)) * 32) + pp * 8));
+                        const short4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                            (__attribute__((address_space(3))) short4_t*)(Ds + r2 * ROWB + ((blk ^ tr_func(r2)) * 32) + pp * 8));
+                        bf[n] = short8_t{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                    }
+#pragma unroll
+                    for (int m = 0; m < 4; ++m)
+#pragma unroll
+                        for (int n = 0; n < 4; ++n)
+                            acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[m], bf[n], acc[m][n], 0, 0, 0);
+                }
+            } else {
+                for (int ks = 0; ks < KPIX / 4; ++ks) {
+                    const int r = ks * 4 + lg;
+                    float af[4], bf[4];
+#pragma unroll
+                    for (int m = 0; m < 4; ++m)
+                        af[m] = *reinterpret_cast<const float*>(Xs + r * ROWB + ((wm * 4 + m) * 16 + li) * 4);
+#pragma unroll
+                    for (int n = 0; n < 4; ++n)
+                        bf[n] = *reinterpret_cast<const float*>(Ds + r * ROWB + ((wn * 4 + n) * 16 + li) * 4);
+#pragma unroll
+                    for (int m = 0; m < 4; ++m)
+#pragma unroll
+                        for (int n = 0; n < 4; ++n)
+                            acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[m], bf[n], acc[m][n], 0, 0, 0);
+                }
+            }
+        }
+    }
+
+    float* slab = p.slabs + ((long long)blockIdx.y * p.kh * p.kw + tap) * p.cin * p.cout;
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int n = 0; n < 4; ++n)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int ci = m0 + (wm * 4 + m) * 16 + lg * 4 + r;
+                const int co = n0 + (wn * 4 + n) * 16 + li;
+                if (ci < p.cin && co < p.cout) slab[(long long)ci * p.cout + co] = acc[m][n][r];
+            }
+}
+
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slabs, int splits, long long n,
+                                                           float* __restrict__ dw, int accumulate) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        float s = accumulate ? dw[i] : 0.f;
+        for (int k = 0; k < splits; ++k) s += slabs[(long long)k * n + i];
+        dw[i] = s;
+    }
+}
+
+inline int wgrad_splits(int B, int H, int cin, int cout, int taps) {
+    const long long tiles = (long long)taps * cutie::cdiv(cin, 128) * cutie::cdiv(cout, 128);
+    long long s = 1024 / tiles;
+    if (s > 64) s = 64;
+    if (s > (long long)B * H) s = (long long)B * H;
+    if (s < 1) s = 1;
+    return (int)s;
+}
+
+template <int DT, int ODT>
+int launch_conv(const ConvParams& p, size_t lds, hipStream_t stream) {
+    const void* fn = (const void*)conv_kernel<DT, ODT>;
+    if (lds > 64 * 1024) CUTIE_CHECK_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const long long grid = (long long)p.B * p.tiles_h * p.tiles_w * p.n_tiles_n;
+    hipLaunchKernelGGL((conv_kernel<DT, ODT>), dim3((unsigned)grid), dim3(256), lds, stream, p);
+    CUTIE_CHECK_LAUNCH();
+    return CUTIE_OK;
+}
+
+}  // namespace
+
+extern "C" int cutie_conv_fwd(const cutie_conv_seg* segs, int n_segs, int B, int H, int W, int n_out, void* out,
+                              int ld_out, int out_dtype, const float* bias, int relu, float* stats, int dtype,
+                              cutie_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    CUTIE_CHECK_ARG(segs && n_segs >= 1 && n_segs <= CUTIE_MAX_SEGS, "conv_fwd: n_segs=%d (1..%d)", n_segs, CUTIE_MAX_SEGS);
+    CUTIE_CHECK_ARG(B >= 0 && H >= 1 && W >= 1 && n_out >= 1 && ld_out >= n_out, "conv_fwd: bad sizes B=%d H=%d W=%d n_out=%d ld_out=%d",
+                    B, H, W, n_out, ld_out);
+    CUTIE_CHECK_ARG(dtype == CUTIE_F32 || dtype == CUTIE_BF16, "conv_fwd: dtype %d", dtype);
+    CUTIE_CHECK_ARG(out_dtype == CUTIE_F32 || out_dtype == CUTIE_BF16, "conv_fwd: out_dtype %d", out_dtype);
+    if (B == 0) return CUTIE_OK;
+    CUTIE_CHECK_ARG(out, "conv_fwd: null output");
+    const int es = dtype == CUTIE_BF16 ? 2 : 4;
+    const int bke = dtype == CUTIE_BF16 ? 64 : 32;
+
+    ConvParams p;
+    p.nseg = n_segs;
+    int twb = 1;
+    while (twb < 8 && twb * 16 < W) twb *= 2;
+    p.TWB = twb;
+    p.TH = 8 / twb;
+    p.tiles_h = (int)cutie::cdiv(H, p.TH);
+    p.tiles_w = (int)cutie::cdiv(W, twb * 16);
+    p.n_tiles_n = (int)cutie::cdiv(n_out, 128);
+    int a_bytes = 0;
+    for (int s = 0; s < n_segs; ++s) {
+        const cutie_conv_seg& g = segs[s];
+        CUTIE_CHECK_ARG(g.x && g.w, "conv_fwd: segment %d has a null pointer", s);
+        CUTIE_CHECK_ARG(g.kh >= 1 && g.kw >= 1 && (g.kh & 1) && (g.kw & 1) && g.dil >= 1,
+                        "conv_fwd: segment %d kernel %dx%d dil %d (odd sizes, dil >= 1)", s, g.kh, g.kw, g.dil);
+        CUTIE_CHECK_ARG(g.cin >= bke && g.cin % bke == 0, "conv_fwd: segment %d cin=%d must be a multiple of %d (zero pad)", s,
+                        g.cin, bke);
+        CUTIE_CHECK_ARG(g.ld_x >= g.cin && (g.ld_x * es) % 16 == 0 && cutie::aligned16(g.x) && cutie::aligned16(g.w),
+                        "conv_fwd: segment %d needs 16-byte aligned rows (ld_x=%d)", s, g.ld_x);
+        CUTIE_CHECK_ARG(g.w_tap_stride >= (int64_t)n_out * g.cin, "conv_fwd: segment %d w_tap_stride too small", s);
+        Seg& d = p.seg[s];
+        d.x = (const char*)g.x; d.w = (const char*)g.w; d.w_tap_stride = g.w_tap_stride;
+        d.ld_x = g.ld_x; d.cin = g.cin; d.kh = g.kh; d.kw = g.kw; d.dil = g.dil; d.sgn = g.flip ? -1 : 1;
+        const int pw = twb * 16 + 2 * (g.kw / 2) * g.dil;
+        const int bytes = p.TH * pw * 128;
+        if (bytes > a_bytes) a_bytes = bytes;
+    }
+    p.a_bytes = a_bytes;
+    p.B = B; p.H = H; p.W = W; p.n_out = n_out;
+    p.out = (char*)out; p.ld_out = ld_out; p.bias = bias; p.relu = relu; p.stats = stats;
+    const size_t oes = out_dtype == CUTIE_BF16 ? 2 : 4;
+    size_t lds = (size_t)a_bytes + 128 * 128;
+    if (lds < 128 * 128 * oes) lds = 128 * 128 * oes;
+    CUTIE_CHECK_ARG(lds <= 160 * 1024, "conv_fwd: tile needs %zu B of LDS (dilation %d too large for W=%d)", lds,
+                    segs[0].dil, W);
+    CUTIE_CHECK_ARG((long long)B * p.tiles_h * p.tiles_w * p.n_tiles_n < (1ll << 31), "conv_fwd: grid too large");
+    if (dtype == CUTIE_BF16) {
+        if (out_dtype == CUTIE_BF16) return launch_conv<CUTIE_BF16, CUTIE_BF16>(p, lds, stream);
+        return launch_conv<CUTIE_BF16, CUTIE_F32>(p, lds, stream);
+    }
+    if (out_dtype == CUTIE_BF16) return launch_conv<CUTIE_F32, CUTIE_BF16>(p, lds, stream);
+    return launch_conv<CUTIE_F32, CUTIE_F32>(p, lds, stream);
+}
+
+extern "C" size_t cutie_conv_wgrad_workspace_bytes(int B, int H, int /*W*/, int cin, int cout, int kh, int kw) {
+    if (B < 1 || H < 1 || cin < 1 || cout < 1 || kh < 1 || kw < 1) return 0;
+    return (size_t)wgrad_splits(B, H, cin, cout, kh * kw) * kh * kw * cin * cout * sizeof(float);
+}
+
+extern "C" int cutie_conv_wgrad(const void* x, int ld_x, int cin, const void* dz, int ld_dz, int cout, int B, int H,
+                                int W, int kh, int kw, int dil, float* dw, int accumulate, int dtype, void* workspace,
+                                size_t workspace_bytes, cutie_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    CUTIE_CHECK_ARG(B >= 0 && H >= 1 && W >= 1 && cin >= 1 && cout >= 1, "conv_wgrad: bad sizes");
+    CUTIE_CHECK_ARG(kh >= 1 && kw >= 1 && (kh & 1) && (kw & 1) && dil >= 1, "conv_wgrad: kernel %dx%d dil %d", kh, kw, dil);
+    CUTIE_CHECK_ARG(dtype == CUTIE_F32 || dtype == CUTIE_BF16, "conv_wgrad: dtype %d", dtype);
+    const int es = dtype == CUTIE_BF16 ? 2 : 4;
+    const int epc = 16 / es;
+    CUTIE_CHECK_ARG(ld_x >= cin && ld_dz >= cout && (ld_x * es) % 16 == 0 && (ld_dz * es) % 16 == 0,
+                    "conv_wgrad: rows must be 16-byte multiples (ld_x=%d ld_dz=%d)", ld_x, ld_dz);
+    // a 16-byte chunk is loaded whenever its first channel is valid: the view must be readable
+    // up to the chunk end (ld covers it) and hold zeros there
+    CUTIE_CHECK_ARG(cutie::cdiv(cin, epc) * epc <= ld_x && cutie::cdiv(cout, epc) * epc <= ld_dz,
+                    "conv_wgrad: ld must cover cin/cout rounded up to %d channels (zero padded)", epc);
+    if (B == 0) {
+        if (!accumulate) CUTIE_CHECK_HIP(hipMemsetAsync(dw, 0, (size_t)kh * kw * cin * cout * 4, stream));
+        return CUTIE_OK;
+    }
+    CUTIE_CHECK_ARG(x && dz && dw && cutie::aligned16(x) && cutie::aligned16(dz), "conv_wgrad: null or misaligned pointer");
+    const size_t need = cutie_conv_wgrad_workspace_bytes(B, H, W, cin, cout, kh, kw);
+    if (!workspace || workspace_bytes < need) {
+        cutie::set_error("conv_wgrad: workspace %zu < %zu", workspace_bytes, need);
+        return CUTIE_E_WORKSPACE;
+    }
+    WgradParams p;
+    p.x = (const char*)x; p.dz = (const char*)dz; p.ld_x = ld_x; p.cin = cin; p.ld_dz = ld_dz; p.cout = cout;
+    p.B = B; p.H = H; p.W = W; p.kh = kh; p.kw = kw; p.dil = dil;
+    p.slabs = (float*)workspace;
+    p.splits = wgrad_splits(B, H, cin, cout, kh * kw);
+    p.mt = (int)cutie::cdiv(cin, 128);
+    p.ntile = (int)cutie::cdiv(cout, 128);
+    const dim3 grid(kh * kw * p.mt * p.ntile, p.splits);
+    const size_t lds = (size_t)2 * 64 * 128 * es;
+    if (dtype == CUTIE_BF16) {
+        hipLaunchKernelGGL(wgrad_kernel<CUTIE_BF16>, grid, dim3(256), lds, stream, p);
+    } else {
+        hipLaunchKernelGGL(wgrad_kernel<CUTIE_F32>, grid, dim3(256), lds, stream, p);
+    }
+    CUTIE_CHECK_LAUNCH();
+    const long long n = (long long)kh * kw * cin * cout;
+    long long g = cutie::cdiv(n, 256);
+    if (g > 4096) g = 4096;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)g), dim3(256), 0, stream, (const float*)workspace, p.splits, n,
+                       dw, accumulate);
+    CUTIE_CHECK_LAUNCH();
+    return CUTIE_OK;
+}

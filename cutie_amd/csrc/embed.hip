@@ -1,0 +1,184 @@
+// K1 / K13: embedding gather (+ its scatter-add gradient), batch gather, dtype convert.
+// All HBM-bound row copies: one lane moves 4 consecutive elements, a row is read by
+// consecutive lanes (model_framework.py:43-54, :73-86).
+#include "common.h"
+
+namespace {
+using namespace cutie;
+
+template <int ODT>
+__global__ __launch_bounds__(256) void embed_fwd_kernel(const int32_t* __restrict__ ids, int64_t n_cells,
+                                                        const float* __restrict__ table, int V, int E4,
+                                                        typename elem<ODT>::type* __restrict__ out,
+                                                        int ld_out, int32_t* oob) {
+    const int64_t total = n_cells * E4;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t cell = idx / E4;
+        const int q = (int)(idx - cell * E4);
+        const int id = ids[cell];
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (id >= 0 && id < V) {
+            v = *reinterpret_cast<const float4*>(table + (int64_t)id * E4 * 4 + q * 4);
+        } else if (q == 0) {
+            atomicAdd(oob, 1);
+        }
+        store4(out + cell * ld_out + q * 4, v);
+    }
+}
+
+// dtable[id] += dout[cell]; ids 0/1 are summed in registers, then LDS, then one atomic per WG
+template <int DT>
+__global__ __launch_bounds__(256) void embed_bwd_kernel(const int32_t* __restrict__ ids, int64_t n_cells,
+                                                        const typename elem<DT>::type* __restrict__ dout,
+                                                        int ld, float* __restrict__ dtable, int V, int E4,
+                                                        int cells_per_wg) {
+    __shared__ float4 red[2][256];
+    const int rows_par = 256 / E4;        // rows handled side by side
+    const int q = threadIdx.x % E4;
+    const int sub = threadIdx.x / E4;
+    const bool active = sub < rows_par;
+    float4 acc0 = make_float4(0.f, 0.f, 0.f, 0.f), acc1 = acc0;
+    const int64_t c0 = (int64_t)blockIdx.x * cells_per_wg;
+    const int64_t c1 = (c0 + cells_per_wg < n_cells) ? c0 + cells_per_wg : n_cells;
+    if (active) {
+        for (int64_t cell = c0 + sub; cell < c1; cell += rows_par) {
+            const int id = ids[cell];
+            if (id < 0 || id >= V) continue;
+            const float4 g = load4(dout + cell * ld + q * 4);
+            if (id == 0) {
+                acc0.x += g.x; acc0.y += g.y; acc0.z += g.z; acc0.w += g.w;
+            } else if (id == 1) {
+                acc1.x += g.x; acc1.y += g.y; acc1.z += g.z; acc1.w += g.w;
+            } else {
+                float* dst = dtable + (int64_t)id * E4 * 4 + q * 4;
+                atomicAdd(dst + 0, g.x); atomicAdd(dst + 1, g.y);
+                atomicAdd(dst + 2, g.z); atomicAdd(dst + 3, g.w);
+            }
+        }
+    }
+    red[0][threadIdx.x] = acc0;
+    red[1][threadIdx.x] = acc1;
+    __syncthreads();
+    if (threadIdx.x < E4) {
+        float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0;
+        for (int s = 0; s < rows_par; ++s) {
+            const float4 a = red[0][s * E4 + q], b = red[1][s * E4 + q];
+            s0.x += a.x; s0.y += a.y; s0.z += a.z; s0.w += a.w;
+            s1.x += b.x; s1.y += b.y; s1.z += b.z; s1.w += b.w;
+        }
+        float* d0 = dtable + q * 4;
+        atomicAdd(d0 + 0, s0.x); atomicAdd(d0 + 1, s0.y); atomicAdd(d0 + 2, s0.z); atomicAdd(d0 + 3, s0.w);
+        if (V > 1) {
+            float* d1 = dtable + (int64_t)E4 * 4 + q * 4;
+            atomicAdd(d1 + 0, s1.x); atomicAdd(d1 + 1, s1.y); atomicAdd(d1 + 2, s1.z); atomicAdd(d1 + 3, s1.w);
+        }
+    }
+}
+
+template <int DT>
+__global__ __launch_bounds__(256) void batch_gather_kernel(const typename elem<DT>::type* __restrict__ feat,
+                                                           int ld_feat, int n_src, const int32_t* __restrict__ idx,
+                                                           int n_cells, int B, int C4,
+                                                           typename elem<DT>::type* __restrict__ out, int ld_out) {
+    const int64_t total = (int64_t)B * n_cells * C4;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total;
+         t += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t cell = t / C4;  // b*n_cells + cell
+        const int q = (int)(t - cell * C4);
+        const int b = (int)(cell / n_cells);
+        int s = idx[cell];
+        s = s < 0 ? 0 : (s >= n_src ? n_src - 1 : s);
+        const float4 v = load4(feat + ((int64_t)b * n_src + s) * ld_feat + q * 4);
+        store4(out + cell * ld_out + q * 4, v);
+    }
+}
+
+template <int SDT, int DDT>
+__global__ __launch_bounds__(256) void convert_kernel(const typename elem<SDT>::type* __restrict__ src, int ld_src,
+                                                      typename elem<DDT>::type* __restrict__ dst, int ld_dst,
+                                                      int64_t n_rows, int C4) {
+    const int64_t total = n_rows * C4;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total;
+         t += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = t / C4;
+        const int q = (int)(t - r * C4);
+        store4(dst + r * ld_dst + q * 4, load4(src + r * ld_src + q * 4));
+    }
+}
+
+inline int grid_for(int64_t work_items) {
+    int64_t g = cutie::cdiv(work_items, 256);
+    if (g > 2048) g = 2048;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+}  // namespace
+
+extern "C" int cutie_embed_fwd(const int32_t* ids, int64_t n_cells, const float* table, int V, int E,
+                               void* out, int ld_out, int out_dtype, int32_t* oob_count,
+                               cutie_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    CUTIE_CHECK_ARG(n_cells >= 0 && V >= 1 && E >= 4 && (E % 4) == 0, "embed_fwd: n_cells=%lld V=%d E=%d (E %% 4 == 0 needed)",
+                    (long long)n_cells, V, E);
+    CUTIE_CHECK_ARG(ld_out >= E && (ld_out % 4) == 0, "embed_fwd: ld_out=%d must be >= E and a multiple of 4", ld_out);
+    if (n_cells == 0) return CUTIE_OK;
+    CUTIE_CHECK_ARG(ids && table && out && oob_count, "embed_fwd: null pointer");
+    CUTIE_CHECK_ARG(cutie::aligned16(table) && ((uintptr_t)out % 8) == 0, "embed_fwd: misaligned pointers");
+    const int g = grid_for(n_cells * (E / 4));
+    CUTIE_DISPATCH_DTYPE(out_dtype, ODT,
+        hipLaunchKernelGGL(embed_fwd_kernel<ODT>, dim3(g), dim3(256), 0, stream, ids, n_cells, table, V, E / 4,
+                           (typename elem<ODT>::type*)out, ld_out, oob_count));
+    CUTIE_CHECK_LAUNCH();
+    return CUTIE_OK;
+}
+
+extern "C" int cutie_embed_bwd(const int32_t* ids, int64_t n_cells, const void* dout, int ld_dout,
+                               int dout_dtype, float* dtable, int V, int E, cutie_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    CUTIE_CHECK_ARG(n_cells >= 0 && V >= 1 && E >= 4 && (E % 4) == 0 && E <= 1024, "embed_bwd: n_cells=%lld V=%d E=%d",
+                    (long long)n_cells, V, E);
+    CUTIE_CHECK_ARG(ld_dout >= E && (ld_dout % 4) == 0, "embed_bwd: ld_dout=%d", ld_dout);
+    if (n_cells == 0) return CUTIE_OK;
+    CUTIE_CHECK_ARG(ids && dout && dtable, "embed_bwd: null pointer");
+    const int cells_per_wg = 512;
+    const int g = (int)cutie::cdiv(n_cells, cells_per_wg);
+    CUTIE_DISPATCH_DTYPE(dout_dtype, DT,
+        hipLaunchKernelGGL(embed_bwd_kernel<DT>, dim3(g), dim3(256), 0, stream, ids, n_cells,
+                           (const typename elem<DT>::type*)dout, ld_dout, dtable, V, E / 4, cells_per_wg));
+    CUTIE_CHECK_LAUNCH();
+    return CUTIE_OK;
+}
+
+extern "C" int cutie_batch_gather(const void* feat, int ld_feat, int n_src, const int32_t* idx, int n_cells,
+                                  int B, int C, void* out, int ld_out, int dtype, cutie_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    CUTIE_CHECK_ARG(B >= 0 && n_cells >= 0 && n_src >= 1 && C >= 4 && (C % 4) == 0, "batch_gather: bad sizes");
+    CUTIE_CHECK_ARG((ld_feat % 4) == 0 && (ld_out % 4) == 0 && ld_feat >= C && ld_out >= C, "batch_gather: bad ld");
+    if (B == 0 || n_cells == 0) return CUTIE_OK;
+    CUTIE_CHECK_ARG(feat && idx && out, "batch_gather: null pointer");
+    const int g = grid_for((int64_t)B * n_cells * (C / 4));
+    CUTIE_DISPATCH_DTYPE(dtype, DT,
+        hipLaunchKernelGGL(batch_gather_kernel<DT>, dim3(g), dim3(256), 0, stream,
+                           (const typename elem<DT>::type*)feat, ld_feat, n_src, idx, n_cells, B, C / 4,
+                           (typename elem<DT>::type*)out, ld_out));
+    CUTIE_CHECK_LAUNCH();
+    return CUTIE_OK;
+}
+
+extern "C" int cutie_convert(const void* src, int ld_src, int src_dtype, void* dst, int ld_dst, int dst_dtype,
+                             int64_t n_rows, int C, cutie_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    CUTIE_CHECK_ARG(n_rows >= 0 && C >= 4 && (C % 4) == 0, "convert: C=%d must be a positive multiple of 4", C);
+    CUTIE_CHECK_ARG((ld_src % 4) == 0 && (ld_dst % 4) == 0 && ld_src >= C && ld_dst >= C, "convert: bad ld");
+    if (n_rows == 0) return CUTIE_OK;
+    CUTIE_CHECK_ARG(src && dst, "convert: null pointer");
+    const int g = grid_for(n_rows * (C / 4));
+    CUTIE_DISPATCH_DTYPE(src_dtype, SDT, CUTIE_DISPATCH_DTYPE(dst_dtype, DDT,
+        hipLaunchKernelGGL((convert_kernel<SDT, DDT>), dim3(g), dim3(256), 0, stream,
+                           (const typename elem<SDT>::type*)src, ld_src, (typename elem<DDT>::type*)dst, ld_dst,
+                           n_rows, C / 4)));
+    CUTIE_CHECK_LAUNCH();
+    return CUTIE_OK;
+}

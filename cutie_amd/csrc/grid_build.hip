@@ -1,0 +1,219 @@
+// K0: OCR tokens -> rows x cols index grid.  One workgroup per document.
+//
+// Follows DataLoader._positional_mapping (/root/reference/data_loader_json.py:437-577):
+//   keys in IEEE double with the reference's operation order (:499-504), the stable sort of
+//   :507 as a rank-by-counting over the total order (row, v_c, h_c, dict_id, input index),
+//   then one lane per grid row replays the sequential slot search / left shift (:512-557).
+// Rows are independent once sorted (strategies 0 and 1 never touch another row), so the
+// sequential part is at most one row's tokens long.  The working grid lives in LDS.
+#include "common.h"
+
+#pragma clang fp contract(off)
+
+namespace {
+
+struct GridArgs {
+    const int32_t* tok_box;
+    const int32_t* tok_id;
+    const int32_t* tok_ecid;
+    const int32_t* doc_extent;
+    const int32_t* doc_off;
+    int rows, cols, strategy;
+    int32_t* grid;
+    int8_t* labels;
+    int32_t* ps_x;
+    int32_t* ps_y;
+    int32_t* tok_order;
+    int32_t* tok_place;
+    int32_t* status;
+    double* key_v;   // workspace [T]
+    double* key_h;   // workspace [T]
+    int32_t* key_row;  // workspace [T]
+    int32_t* key_col;  // workspace [T]
+};
+
+__device__ __forceinline__ bool key_less(int rj, double vj, double hj, int dj, int j,
+                                         int ri, double vi, double hi, int di, int i) {
+    if (rj != ri) return rj < ri;
+    if (vj != vi) return vj < vi;
+    if (hj != hi) return hj < hi;
+    if (dj != di) return dj < di;
+    return j < i;
+}
+
+__global__ __launch_bounds__(256) void grid_build_kernel(GridArgs a) {
+    extern __shared__ __attribute__((aligned(16))) int32_t lds[];
+    const int rows = a.rows, cols = a.cols;
+    int32_t* g = lds;                       // [rows*cols]
+    int32_t* row_start = lds + rows * cols; // [rows]
+    int32_t* flag = row_start + rows;       // [1]
+
+    const int doc = blockIdx.x;
+    const int t0 = a.doc_off[doc];
+    const int n = a.doc_off[doc + 1] - t0;
+    const int tid = threadIdx.x;
+
+    for (int i = tid; i < rows * cols; i += blockDim.x) g[i] = 0;
+    for (int i = tid; i < rows; i += blockDim.x) row_start[i] = -1;
+    if (tid == 0) *flag = 0;
+    __syncthreads();
+
+    const int left = a.doc_extent[doc * 4 + 0], top = a.doc_extent[doc * 4 + 1];
+    const int right = a.doc_extent[doc * 4 + 2], bottom = a.doc_extent[doc * 4 + 3];
+
+    // ---- keys (:499-504)
+    for (int i = tid; i < n; i += blockDim.x) {
+        const int x_left = a.tok_box[(t0 + i) * 4 + 0], y_top = a.tok_box[(t0 + i) * 4 + 1];
+        const int x_right = a.tok_box[(t0 + i) * 4 + 2], y_bottom = a.tok_box[(t0 + i) * 4 + 3];
+        bool bad = (bottom == top) || (right == left);
+        double v_c = 0.0, h_c = 0.0;
+        int row = 0, col = 0;
+        if (!bad) {
+            v_c = ((double)(y_top - top) + (double)(y_bottom - y_top) / 2.0) / (double)(bottom - top);
+            h_c = ((double)(x_left - left) + (double)(x_right - x_left) / 2.0) / (double)(right - left);
+            const double fr = (double)rows * v_c, fc = (double)cols * h_c;
+            // int() truncates toward zero; anything that lands outside the grid is an error
+            bad = !(fr > -1.0 && fr < (double)rows && fc > -1.0 && fc < (double)cols);
+            if (!bad) {  // (-1,0) truncates to 0 and stays inside, as Python's int() does
+                row = (int)fr;
+                col = (int)fc;
+            }
+        }
+        if (bad) atomicOr(flag, 1);
+        a.key_v[t0 + i] = v_c;
+        a.key_h[t0 + i] = h_c;
+        a.key_row[t0 + i] = row;
+        a.key_col[t0 + i] = col;
+    }
+    __syncthreads();  // workgroup-scope fence: the keys are re-read below by other lanes
+    if (*flag) {
+        if (tid == 0) a.status[doc] = 1;
+        for (int i = tid; i < rows * cols; i += blockDim.x) a.grid[(size_t)doc * rows * cols + i] = 0;
+        return;
+    }
+
+    // ---- stable sort (:507) as a rank by counting; all lanes read key j together
+    for (int i = tid; i < n; i += blockDim.x) {
+        const int ri = a.key_row[t0 + i];
+        const double vi = a.key_v[t0 + i], hi = a.key_h[t0 + i];
+        const int di = a.tok_id[t0 + i];
+        int rank = 0;
+        for (int j = 0; j < n; ++j) {
+            rank += key_less(a.key_row[t0 + j], a.key_v[t0 + j], a.key_h[t0 + j], a.tok_id[t0 + j], j,
+                             ri, vi, hi, di, i) ? 1 : 0;
+        }
+        a.tok_order[t0 + rank] = i;
+    }
+    __syncthreads();
+
+    // ---- first sorted position of every row
+    for (int p = tid; p < n; p += blockDim.x) {
+        const int r = a.key_row[t0 + a.tok_order[t0 + p]];
+        if (p == 0 || a.key_row[t0 + a.tok_order[t0 + p - 1]] != r) row_start[r] = p;
+    }
+    __syncthreads();
+
+    // ---- one lane per row replays the sequential placement (:508-557)
+    const size_t cell0 = (size_t)doc * rows * cols;
+    for (int r = tid; r < rows; r += blockDim.x) {
+        int p = row_start[r];
+        if (p < 0) continue;
+        int32_t* gr = g + r * cols;
+        for (; p < n; ++p) {
+            const int i = a.tok_order[t0 + p];
+            if (a.key_row[t0 + i] != r) break;
+            int col = a.key_col[t0 + i];
+            const int dict_id = a.tok_id[t0 + i];
+            while (col < cols && gr[col] != 0) ++col;
+            bool write = true;
+            if (a.strategy == 0) {
+                if (col == cols) write = false;  // :519 overlap, token skipped
+            } else {
+                if (col == cols) {                // :532-539 shift left from the first free cell
+                    col -= 1;
+                    int ptr = 0;
+                    while (ptr < cols && gr[ptr] != 0) ++ptr;
+                    if (ptr == cols) ptr = 0;
+                    for (int c = ptr; c < cols - 1; ++c) gr[c] = gr[c + 1];
+                    gr[cols - 1] = 0;             // what the reference pulls in from its buffer half
+                }
+            }
+            if (write) {
+                gr[col] = dict_id;
+                a.labels[cell0 + r * cols + col] = (int8_t)a.tok_ecid[t0 + i];  // int8 wrap
+                if (a.strategy != 0) {
+                    const int x_left = a.tok_box[(t0 + i) * 4 + 0], y_top = a.tok_box[(t0 + i) * 4 + 1];
+                    const int y_bottom = a.tok_box[(t0 + i) * 4 + 3];
+                    const double box_y = (double)y_top + (double)(y_bottom - y_top) / 2.0;
+                    a.ps_x[cell0 + r * cols + col] = x_left;
+                    a.ps_y[cell0 + r * cols + col] = (int)box_y;
+                }
+                a.tok_place[(t0 + p) * 2 + 0] = r;
+                a.tok_place[(t0 + p) * 2 + 1] = col;
+            } else {
+                a.tok_place[(t0 + p) * 2 + 0] = -1;
+                a.tok_place[(t0 + p) * 2 + 1] = -1;
+            }
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < rows * cols; i += blockDim.x) a.grid[cell0 + i] = g[i];
+    if (tid == 0) a.status[doc] = 0;
+}
+
+}  // namespace
+
+extern "C" size_t cutie_grid_build_workspace_bytes(int n_tokens) {
+    size_t t = (size_t)(n_tokens > 0 ? n_tokens : 1);
+    return t * (8 + 8 + 4 + 4) + 64;
+}
+
+extern "C" int cutie_grid_build(const int32_t* tok_box, const int32_t* tok_id, const int32_t* tok_ecid,
+                                const int32_t* doc_extent, const int32_t* doc_off, int n_docs,
+                                int n_tokens, int rows, int cols, int strategy, int32_t* grid,
+                                int8_t* labels, int32_t* ps_x, int32_t* ps_y, int32_t* tok_order,
+                                int32_t* tok_place, int32_t* status, void* workspace,
+                                size_t workspace_bytes, cutie_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    CUTIE_CHECK_ARG(n_docs >= 0 && n_tokens >= 0, "grid_build: negative sizes");
+    CUTIE_CHECK_ARG(rows >= 1 && cols >= 1 && rows <= 1024, "grid_build: rows=%d cols=%d out of range", rows, cols);
+    CUTIE_CHECK_ARG(strategy == 0 || strategy == 1,
+                    "grid_build: positional_mapping_strategy %d is not built (0 and 1 are)", strategy);
+    const size_t lds_bytes = ((size_t)rows * cols + rows + 4) * sizeof(int32_t);
+    CUTIE_CHECK_ARG(lds_bytes <= 160 * 1024, "grid_build: %dx%d grid needs %zu B of LDS (max 163840)", rows,
+                    cols, lds_bytes);
+    if (n_docs == 0) return CUTIE_OK;
+    CUTIE_CHECK_ARG(grid && labels && ps_x && ps_y && tok_order && tok_place && status && doc_off && doc_extent,
+                    "grid_build: null pointer");
+    CUTIE_CHECK_ARG(n_tokens == 0 || (tok_box && tok_id && tok_ecid), "grid_build: null token arrays");
+    if (workspace_bytes < cutie_grid_build_workspace_bytes(n_tokens) || !workspace) {
+        cutie::set_error("grid_build: workspace %zu < %zu", workspace_bytes,
+                         cutie_grid_build_workspace_bytes(n_tokens));
+        return CUTIE_E_WORKSPACE;
+    }
+    const size_t cells = (size_t)n_docs * rows * cols;
+    CUTIE_CHECK_HIP(hipMemsetAsync(labels, 0, cells, stream));
+    CUTIE_CHECK_HIP(hipMemsetAsync(ps_x, 0, cells * 4, stream));
+    CUTIE_CHECK_HIP(hipMemsetAsync(ps_y, 0, cells * 4, stream));
+
+    GridArgs a;
+    a.tok_box = tok_box; a.tok_id = tok_id; a.tok_ecid = tok_ecid;
+    a.doc_extent = doc_extent; a.doc_off = doc_off;
+    a.rows = rows; a.cols = cols; a.strategy = strategy;
+    a.grid = grid; a.labels = labels; a.ps_x = ps_x; a.ps_y = ps_y;
+    a.tok_order = tok_order; a.tok_place = tok_place; a.status = status;
+    const size_t t = (size_t)(n_tokens > 0 ? n_tokens : 1);
+    char* ws = (char*)(((uintptr_t)workspace + 15) & ~(uintptr_t)15);
+    a.key_v = (double*)ws;
+    a.key_h = a.key_v + t;
+    a.key_row = (int32_t*)(a.key_h + t);
+    a.key_col = a.key_row + t;
+
+    if (lds_bytes > 64 * 1024) {
+        CUTIE_CHECK_HIP(hipFuncSetAttribute((const void*)grid_build_kernel,
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    }
+    hipLaunchKernelGGL(grid_build_kernel, dim3(n_docs), dim3(256), lds_bytes, stream, a);
+    CUTIE_CHECK_LAUNCH();
+    return CUTIE_OK;
+}

@@ -1,0 +1,341 @@
+// K6 / K8: instance norm (center=False, scale=False, eps 1e-6, biased variance) forward and
+// backward, and the global-pool broadcast.  tf.contrib.layers.instance_norm at
+// /root/reference/model_framework.py:423; Model.global_pool at :309-315.
+//
+// All are HBM-bound passes over [B][HW][C] views.  One lane owns VEC consecutive channels;
+// a workgroup covers `rows_par` pixels side by side and walks a slice of HW, so every
+// per-(b,c) reduction is: registers -> LDS across the side-by-side rows -> one f32 atomic.
+#include "common.h"
+
+namespace {
+using namespace cutie;
+
+template <int VEC> struct vecf { float v[VEC]; };
+
+template <int VEC, typename T> __device__ __forceinline__ vecf<VEC> loadv(const T* p) {
+    vecf<VEC> r;
+    if constexpr (VEC == 4) {
+        const float4 f = load4(p);
+        r.v[0] = f.x; r.v[1] = f.y; r.v[2] = f.z; r.v[3] = f.w;
+    } else {
+        r.v[0] = load_as_f32(p);
+    }
+    return r;
+}
+template <int VEC, typename T> __device__ __forceinline__ void storev(T* p, const vecf<VEC>& r) {
+    if constexpr (VEC == 4) {
+        store4(p, make_float4(r.v[0], r.v[1], r.v[2], r.v[3]));
+    } else {
+        store_from_f32(p, r.v[0]);
+    }
+}
+
+struct Map {      // workgroup -> (b, hw slice); thread -> (channel lane, side-by-side row)
+    int b, hw0, hw1, cl, sub, rows_par;
+    bool active;
+};
+__device__ __forceinline__ Map make_map(int HW, int CV) {
+    Map m;
+    m.b = blockIdx.y;
+    const int per = (HW + gridDim.x - 1) / gridDim.x;
+    m.hw0 = blockIdx.x * per;
+    m.hw1 = min(HW, m.hw0 + per);
+    m.rows_par = 256 / CV;
+    m.cl = threadIdx.x % CV;
+    m.sub = threadIdx.x / CV;
+    m.active = m.sub < m.rows_par;
+    return m;
+}
+
+__device__ __forceinline__ void mean_inv(const float* stats, int b, int C, int c, float inv_n, float eps,
+                                         float& mean, float& inv) {
+    const float s = stats[((int64_t)b * C + c) * 2 + 0];
+    const float ss = stats[((int64_t)b * C + c) * 2 + 1];
+    mean = s * inv_n;
+    const float var = fmaxf(ss * inv_n - mean * mean, 0.f);
+    inv = rsqrtf(var + eps);
+}
+
+// red[NRED][256][VEC] in LDS -> sum over the side-by-side rows -> atomicAdd(dst(c, k))
+template <int VEC, int NRED, typename F>
+__device__ __forceinline__ void block_reduce_atomic(float (*red)[256][VEC], const Map& m, int CV, F&& dst) {
+    __syncthreads();
+    if (threadIdx.x < CV) {
+#pragma unroll
+        for (int k = 0; k < NRED; ++k) {
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+                float s = 0.f;
+                for (int r = 0; r < m.rows_par; ++r) s += red[k][r * CV + threadIdx.x][e];
+                atomicAdd(dst(threadIdx.x * VEC + e, k), s);
+            }
+        }
+    }
+}
+
+template <int VEC, typename TA>
+__global__ __launch_bounds__(256) void in_stats_kernel(const TA* __restrict__ a, int ld_a, int HW, int C,
+                                                       float* __restrict__ stats) {
+    __shared__ float red[2][256][VEC];
+    const int CV = C / VEC;
+    const Map m = make_map(HW, CV);
+    float s[VEC] = {}, ss[VEC] = {};
+    if (m.active) {
+        for (int hw = m.hw0 + m.sub; hw < m.hw1; hw += m.rows_par) {
+            const vecf<VEC> x = loadv<VEC>(a + ((int64_t)m.b * HW + hw) * ld_a + m.cl * VEC);
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) { s[e] += x.v[e]; ss[e] += x.v[e] * x.v[e]; }
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) { red[0][threadIdx.x][e] = s[e]; red[1][threadIdx.x][e] = ss[e]; }
+    const int b = m.b;
+    block_reduce_atomic<VEC, 2>(red, m, CV, [&](int c, int k) { return stats + ((int64_t)b * C + c) * 2 + k; });
+}
+
+template <int VEC, typename TA, typename TY>
+__global__ __launch_bounds__(256) void in_apply_kernel(const TA* __restrict__ a, int ld_a,
+                                                       const float* __restrict__ stats, float eps,
+                                                       TY* __restrict__ y, int ld_y, int HW, int C) {
+    const int CV = C / VEC;
+    const Map m = make_map(HW, CV);
+    if (!m.active) return;
+    const float inv_n = 1.f / (float)HW;
+    float mean[VEC], inv[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) mean_inv(stats, m.b, C, m.cl * VEC + e, inv_n, eps, mean[e], inv[e]);
+    for (int hw = m.hw0 + m.sub; hw < m.hw1; hw += m.rows_par) {
+        const int64_t row = (int64_t)m.b * HW + hw;
+        vecf<VEC> x = loadv<VEC>(a + row * ld_a + m.cl * VEC);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) x.v[e] = (x.v[e] - mean[e]) * inv[e];
+        storev<VEC>(y + row * ld_y + m.cl * VEC, x);
+    }
+}
+
+template <int VEC, typename TD, typename TA>
+__global__ __launch_bounds__(256) void in_bwd_stats_kernel(const TD* __restrict__ dy, int ld_dy,
+                                                           const TA* __restrict__ a, int ld_a,
+                                                           const float* __restrict__ stats, float eps,
+                                                           float* __restrict__ redout, int HW, int C) {
+    __shared__ float red[2][256][VEC];
+    const int CV = C / VEC;
+    const Map m = make_map(HW, CV);
+    float s1[VEC] = {}, s2[VEC] = {};
+    if (m.active) {
+        const float inv_n = 1.f / (float)HW;
+        float mean[VEC], inv[VEC];
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) mean_inv(stats, m.b, C, m.cl * VEC + e, inv_n, eps, mean[e], inv[e]);
+        for (int hw = m.hw0 + m.sub; hw < m.hw1; hw += m.rows_par) {
+            const int64_t row = (int64_t)m.b * HW + hw;
+            const vecf<VEC> g = loadv<VEC>(dy + row * ld_dy + m.cl * VEC);
+            const vecf<VEC> x = loadv<VEC>(a + row * ld_a + m.cl * VEC);
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+                s1[e] += g.v[e];
+                s2[e] += g.v[e] * ((x.v[e] - mean[e]) * inv[e]);
+            }
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) { red[0][threadIdx.x][e] = s1[e]; red[1][threadIdx.x][e] = s2[e]; }
+    const int b = m.b;
+    block_reduce_atomic<VEC, 2>(red, m, CV, [&](int c, int k) { return redout + ((int64_t)b * C + c) * 2 + k; });
+}
+
+template <int VEC, typename TD, typename TA, typename TZ>
+__global__ __launch_bounds__(256) void in_bwd_apply_kernel(const TD* __restrict__ dy, int ld_dy,
+                                                           const TA* __restrict__ a, int ld_a,
+                                                           const float* __restrict__ stats, float eps,
+                                                           const float* __restrict__ redin, int relu,
+                                                           TZ* __restrict__ dz, int ld_dz,
+                                                           float* __restrict__ dbias, int HW, int C) {
+    __shared__ float red[1][256][VEC];
+    const int CV = C / VEC;
+    const Map m = make_map(HW, CV);
+    float sb[VEC] = {};
+    if (m.active) {
+        const float inv_n = 1.f / (float)HW;
+        float mean[VEC], inv[VEC], m1[VEC], m2[VEC];
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+            const int c = m.cl * VEC + e;
+            mean_inv(stats, m.b, C, c, inv_n, eps, mean[e], inv[e]);
+            m1[e] = redin[((int64_t)m.b * C + c) * 2 + 0] * inv_n;
+            m2[e] = redin[((int64_t)m.b * C + c) * 2 + 1] * inv_n;
+        }
+        for (int hw = m.hw0 + m.sub; hw < m.hw1; hw += m.rows_par) {
+            const int64_t row = (int64_t)m.b * HW + hw;
+            const vecf<VEC> g = loadv<VEC>(dy + row * ld_dy + m.cl * VEC);
+            const vecf<VEC> x = loadv<VEC>(a + row * ld_a + m.cl * VEC);
+            vecf<VEC> o;
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+                const float xh = (x.v[e] - mean[e]) * inv[e];
+                float d = inv[e] * (g.v[e] - m1[e] - xh * m2[e]);
+                if (relu && !(x.v[e] > 0.f)) d = 0.f;
+                o.v[e] = d;
+                sb[e] += d;
+            }
+            storev<VEC>(dz + row * ld_dz + m.cl * VEC, o);
+        }
+    }
+    if (dbias) {
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) red[0][threadIdx.x][e] = sb[e];
+        block_reduce_atomic<VEC, 1>(red, m, CV, [&](int c, int) { return dbias + c; });
+    }
+}
+
+// one workgroup per (b, chunk of CV_BLK channel lanes): mean over HW, then broadcast
+template <int VEC, typename TX, typename TO>
+__global__ __launch_bounds__(256) void mean_bcast_kernel(const TX* __restrict__ x, int ld_x, TO* __restrict__ out,
+                                                         int ld_out, int HW, int C, int cv_blk) {
+    __shared__ float red[256][VEC];
+    __shared__ float mean_s[256][VEC];
+    const int b = blockIdx.y;
+    const int rows_par = 256 / cv_blk;
+    const int cl = threadIdx.x % cv_blk, sub = threadIdx.x / cv_blk;
+    const int c0 = (blockIdx.x * cv_blk + cl) * VEC;
+    const bool active = sub < rows_par && c0 < C;
+    float s[VEC] = {};
+    if (active) {
+        for (int hw = sub; hw < HW; hw += rows_par) {
+            const vecf<VEC> v = loadv<VEC>(x + ((int64_t)b * HW + hw) * ld_x + c0);
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) s[e] += v.v[e];
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) red[threadIdx.x][e] = s[e];
+    __syncthreads();
+    if (threadIdx.x < cv_blk) {
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+            float t = 0.f;
+            for (int r = 0; r < rows_par; ++r) t += red[r * cv_blk + threadIdx.x][e];
+            mean_s[threadIdx.x][e] = t / (float)HW;
+        }
+    }
+    __syncthreads();
+    if (active) {
+        vecf<VEC> mv;
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) mv.v[e] = mean_s[cl][e];
+        for (int hw = sub; hw < HW; hw += rows_par) storev<VEC>(out + ((int64_t)b * HW + hw) * ld_out + c0, mv);
+    }
+}
+
+struct Launch { dim3 grid; int vec; };
+inline int pick_vec(int C, std::initializer_list<int> lds, std::initializer_list<const void*> ptrs) {
+    if (C % 4) return 1;
+    for (int l : lds) if (l % 4) return 1;
+    for (const void* p : ptrs) if (p && ((uintptr_t)p % 16)) return 1;
+    return 4;
+}
+inline int check_common(const char* name, int B, int HW, int C, int vec) {
+    if (B < 0 || HW < 1 || C < 1) { cutie::set_error("%s: bad sizes B=%d HW=%d C=%d", name, B, HW, C); return CUTIE_E_ARG; }
+    if (C / vec > 256) { cutie::set_error("%s: C=%d too wide for this layout (max %d)", name, C, 256 * vec); return CUTIE_E_ARG; }
+    return CUTIE_OK;
+}
+inline dim3 reduce_grid(int B, int HW, int C, int vec) {
+    const int rows_par = 256 / (C / vec);
+    int s = HW / (rows_par * 8);
+    const int cap = (2048 + B - 1) / (B > 0 ? B : 1);
+    if (s > cap) s = cap;
+    if (s < 1) s = 1;
+    return dim3(s, B);
+}
+
+}  // namespace
+
+#define NORM_DISPATCH_VEC(vec, ...)                                   \
+    if ((vec) == 4) { constexpr int VEC = 4; __VA_ARGS__; }           \
+    else { constexpr int VEC = 1; __VA_ARGS__; }
+
+extern "C" int cutie_in_stats(const void* a, int ld_a, int a_dtype, int B, int HW, int C, float* stats,
+                              cutie_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    const int vec = pick_vec(C, {ld_a}, {a});
+    if (int e = check_common("in_stats", B, HW, C, vec)) return e;
+    if (B == 0) return CUTIE_OK;
+    CUTIE_CHECK_ARG(a && stats && ld_a >= C, "in_stats: null pointer or ld < C");
+    const dim3 g = reduce_grid(B, HW, C, vec);
+    CUTIE_DISPATCH_DTYPE(a_dtype, ADT, NORM_DISPATCH_VEC(vec,
+        hipLaunchKernelGGL((in_stats_kernel<VEC, typename elem<ADT>::type>), g, dim3(256), 0, stream,
+                           (const typename elem<ADT>::type*)a, ld_a, HW, C, stats)));
+    CUTIE_CHECK_LAUNCH();
+    return CUTIE_OK;
+}
+
+extern "C" int cutie_in_apply(const void* a, int ld_a, int a_dtype, const float* stats, float eps, void* y,
+                              int ld_y, int y_dtype, int B, int HW, int C, cutie_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    const int vec = pick_vec(C, {ld_a, ld_y}, {a, y});
+    if (int e = check_common("in_apply", B, HW, C, vec)) return e;
+    if (B == 0) return CUTIE_OK;
+    CUTIE_CHECK_ARG(a && stats && y && ld_a >= C && ld_y >= C, "in_apply: null pointer or ld < C");
+    const dim3 g = reduce_grid(B, HW, C, vec);
+    CUTIE_DISPATCH_DTYPE(a_dtype, ADT, CUTIE_DISPATCH_DTYPE(y_dtype, YDT, NORM_DISPATCH_VEC(vec,
+        hipLaunchKernelGGL((in_apply_kernel<VEC, typename elem<ADT>::type, typename elem<YDT>::type>), g, dim3(256),
+                           0, stream, (const typename elem<ADT>::type*)a, ld_a, stats, eps,
+                           (typename elem<YDT>::type*)y, ld_y, HW, C))));
+    CUTIE_CHECK_LAUNCH();
+    return CUTIE_OK;
+}
+
+extern "C" int cutie_in_bwd_stats(const void* dy, int ld_dy, int dy_dtype, const void* a, int ld_a, int a_dtype,
+                                  const float* stats, float eps, float* red, int B, int HW, int C,
+                                  cutie_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    const int vec = pick_vec(C, {ld_dy, ld_a}, {dy, a});
+    if (int e = check_common("in_bwd_stats", B, HW, C, vec)) return e;
+    if (B == 0) return CUTIE_OK;
+    CUTIE_CHECK_ARG(dy && a && stats && red && ld_dy >= C && ld_a >= C, "in_bwd_stats: null pointer or ld < C");
+    const dim3 g = reduce_grid(B, HW, C, vec);
+    CUTIE_DISPATCH_DTYPE(dy_dtype, DDT, CUTIE_DISPATCH_DTYPE(a_dtype, ADT, NORM_DISPATCH_VEC(vec,
+        hipLaunchKernelGGL((in_bwd_stats_kernel<VEC, typename elem<DDT>::type, typename elem<ADT>::type>), g,
+                           dim3(256), 0, stream, (const typename elem<DDT>::type*)dy, ld_dy,
+                           (const typename elem<ADT>::type*)a, ld_a, stats, eps, red, HW, C))));
+    CUTIE_CHECK_LAUNCH();
+    return CUTIE_OK;
+}
+
+extern "C" int cutie_in_bwd_apply(const void* dy, int ld_dy, int dy_dtype, const void* a, int ld_a, int a_dtype,
+                                  const float* stats, float eps, const float* red, int relu, void* dz, int ld_dz,
+                                  int dz_dtype, float* dbias, int B, int HW, int C, cutie_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    const int vec = pick_vec(C, {ld_dy, ld_a, ld_dz}, {dy, a, dz});
+    if (int e = check_common("in_bwd_apply", B, HW, C, vec)) return e;
+    if (B == 0) return CUTIE_OK;
+    CUTIE_CHECK_ARG(dy && a && stats && red && dz && ld_dy >= C && ld_a >= C && ld_dz >= C,
+                    "in_bwd_apply: null pointer or ld < C");
+    CUTIE_CHECK_ARG(a_dtype == dz_dtype, "in_bwd_apply: dz dtype must equal a dtype");
+    const dim3 g = reduce_grid(B, HW, C, vec);
+    CUTIE_DISPATCH_DTYPE(dy_dtype, DDT, CUTIE_DISPATCH_DTYPE(a_dtype, ADT, NORM_DISPATCH_VEC(vec,
+        hipLaunchKernelGGL((in_bwd_apply_kernel<VEC, typename elem<DDT>::type, typename elem<ADT>::type,
+                                                typename elem<ADT>::type>), g, dim3(256), 0, stream,
+                           (const typename elem<DDT>::type*)dy, ld_dy, (const typename elem<ADT>::type*)a, ld_a,
+                           stats, eps, red, relu, (typename elem<ADT>::type*)dz, ld_dz, dbias, HW, C))));
+    CUTIE_CHECK_LAUNCH();
+    return CUTIE_OK;
+}
+
+extern "C" int cutie_spatial_mean_bcast(const void* x, int ld_x, int x_dtype, void* out, int ld_out, int out_dtype,
+                                        int B, int HW, int C, cutie_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    const int vec = pick_vec(C, {ld_x, ld_out}, {x, out});
+    CUTIE_CHECK_ARG(B >= 0 && HW >= 1 && C >= 1, "spatial_mean_bcast: bad sizes");
+    if (B == 0) return CUTIE_OK;
+    CUTIE_CHECK_ARG(x && out && ld_x >= C && ld_out >= C, "spatial_mean_bcast: null pointer or ld < C");
+    const int CV = C / vec;
+    const int cv_blk = CV < 16 ? CV : 16;
+    const dim3 g((CV + cv_blk - 1) / cv_blk, B);
+    CUTIE_DISPATCH_DTYPE(x_dtype, XDT, CUTIE_DISPATCH_DTYPE(out_dtype, ODT, NORM_DISPATCH_VEC(vec,
+        hipLaunchKernelGGL((mean_bcast_kernel<VEC, typename elem<XDT>::type, typename elem<ODT>::type>), g, dim3(256),
+                           0, stream, (const typename elem<XDT>::type*)x, ld_x, (typename elem<ODT>::type*)out,
+                           ld_out, HW, C, cv_blk))));
+    CUTIE_CHECK_LAUNCH();
+    return CUTIE_OK;
+}

@@ -1,0 +1,169 @@
+// K12 / K14: L2 regulariser, global-norm pieces and Adam over flat f32 parameter buffers,
+// plus the weight packer that feeds the conv kernels.
+// l2_regularizer /root/reference/model_framework.py:427-432; clip_by_global_norm + Adam
+// /root/reference/main_train_json.py:152-156.  Reductions are two-stage with a fixed grid and
+// a fixed summation order, so every data-parallel replica computes bit-identical norms.
+#include "common.h"
+
+namespace {
+using namespace cutie;
+
+constexpr int RED_BLOCKS = CUTIE_REDUCE_SCRATCH;
+
+__device__ __forceinline__ void block_sum_store(float v, float* dst) {
+    __shared__ float sh[4];
+    v = wave_sum(v);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) *dst = sh[0] + sh[1] + sh[2] + sh[3];
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void sumsq_partial_kernel(const T* __restrict__ x, int64_t n,
+                                                            float* __restrict__ partials) {
+    float s = 0.f;
+    const int64_t n4 = n / 4;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)RED_BLOCKS * 256) {
+        const float4 v = load4(x + i * 4);
+        s += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+    }
+    if (blockIdx.x == 0) {
+        for (int64_t i = n4 * 4 + threadIdx.x; i < n; i += 256) {
+            const float v = load_as_f32(x + i);
+            s += v * v;
+        }
+    }
+    block_sum_store(s, partials + blockIdx.x);
+}
+
+__global__ __launch_bounds__(256) void l2_partial_kernel(const float* __restrict__ w, float* __restrict__ g,
+                                                         int64_t n, float wd, float* __restrict__ partials) {
+    float s = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)RED_BLOCKS * 256) {
+        const float v = w[i];
+        g[i] += wd * v;
+        s += v * v;
+    }
+    block_sum_store(s, partials + blockIdx.x);
+}
+
+__global__ __launch_bounds__(256) void final_sum_kernel(const float* __restrict__ partials, float scale,
+                                                        float* __restrict__ out) {
+    float s = 0.f;
+    for (int i = threadIdx.x; i < RED_BLOCKS; i += 256) s += partials[i];
+    __shared__ float sh[4];
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) *out += scale * (sh[0] + sh[1] + sh[2] + sh[3]);
+}
+
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                   float* __restrict__ m, float* __restrict__ v, int64_t n, float lr_t,
+                                                   float b1, float b2, float eps, const float* __restrict__ gnorm_sq,
+                                                   float clip, float grad_scale) {
+    float scale = grad_scale;
+    if (gnorm_sq) {
+        // tf.clip_by_global_norm: t * clip_norm / max(global_norm, clip_norm)
+        const float norm = sqrtf(*gnorm_sq) * grad_scale;
+        scale = grad_scale * (clip / fmaxf(norm, clip));
+    }
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float gi = g[i] * scale;
+        const float mi = b1 * m[i] + (1.f - b1) * gi;
+        const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+        m[i] = mi;
+        v[i] = vi;
+        p[i] -= lr_t * mi / (sqrtf(vi) + eps);
+    }
+}
+
+// HWIO f32 [tap][cin][cout] -> [tap][cout][cin_pad] (fwd operand) / [tap][cin][cout_pad] (dgrad operand)
+template <typename T>
+__global__ __launch_bounds__(256) void pack_kernel(const float* __restrict__ w, int taps, int cin, int cout,
+                                                   T* __restrict__ w_fwd, int cin_pad, T* __restrict__ w_dg,
+                                                   int cout_pad) {
+    const int64_t n_fwd = w_fwd ? (int64_t)taps * cout * cin_pad : 0;
+    const int64_t n_dg = w_dg ? (int64_t)taps * cin * cout_pad : 0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_fwd + n_dg;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        if (i < n_fwd) {
+            const int c = (int)(i % cin_pad);
+            const int64_t r = i / cin_pad;
+            const int n = (int)(r % cout);
+            const int t = (int)(r / cout);
+            const float v = c < cin ? w[((int64_t)t * cin + c) * cout + n] : 0.f;
+            store_from_f32(w_fwd + i, v);
+        } else {
+            const int64_t j = i - n_fwd;
+            const int n = (int)(j % cout_pad);
+            const int64_t r = j / cout_pad;   // t*cin + c
+            const float v = n < cout ? w[r * cout + n] : 0.f;
+            store_from_f32(w_dg + j, v);
+        }
+    }
+}
+
+}  // namespace
+
+static int launch_final(float* partials, float scale, float* out, hipStream_t stream) {
+    hipLaunchKernelGGL(final_sum_kernel, dim3(1), dim3(256), 0, stream, partials, scale, out);
+    CUTIE_CHECK_LAUNCH();
+    return CUTIE_OK;
+}
+
+extern "C" int cutie_sumsq(const void* x, int64_t n, int dtype, float* out, float* scratch, cutie_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    CUTIE_CHECK_ARG(n >= 0 && out && scratch, "sumsq: bad arguments");
+    if (n == 0) return CUTIE_OK;
+    CUTIE_CHECK_ARG(x && cutie::aligned16(x), "sumsq: x must be 16-byte aligned");
+    CUTIE_DISPATCH_DTYPE(dtype, DT,
+        hipLaunchKernelGGL(sumsq_partial_kernel<typename elem<DT>::type>, dim3(RED_BLOCKS), dim3(256), 0, stream,
+                           (const typename elem<DT>::type*)x, n, scratch));
+    CUTIE_CHECK_LAUNCH();
+    return launch_final(scratch, 1.f, out, stream);
+}
+
+extern "C" int cutie_l2_add(const float* w, float* g, int64_t n, float wd, float* reg_loss, float* scratch,
+                            cutie_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    CUTIE_CHECK_ARG(n >= 0 && reg_loss && scratch, "l2_add: bad arguments");
+    if (n == 0) return CUTIE_OK;
+    CUTIE_CHECK_ARG(w && g, "l2_add: null pointer");
+    hipLaunchKernelGGL(l2_partial_kernel, dim3(RED_BLOCKS), dim3(256), 0, stream, w, g, n, wd, scratch);
+    CUTIE_CHECK_LAUNCH();
+    return launch_final(scratch, 0.5f * wd, reg_loss, stream);
+}
+
+extern "C" int cutie_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr_t, float beta1,
+                               float beta2, float eps, const float* gnorm_sq, float clip, float grad_scale,
+                               cutie_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    CUTIE_CHECK_ARG(n >= 0, "adam_step: n < 0");
+    if (n == 0) return CUTIE_OK;
+    CUTIE_CHECK_ARG(p && g && m && v, "adam_step: null pointer");
+    int64_t grid = cutie::cdiv(n, 256);
+    if (grid > 4096) grid = 4096;
+    hipLaunchKernelGGL(adam_kernel, dim3((int)grid), dim3(256), 0, stream, p, g, m, v, n, lr_t, beta1, beta2, eps,
+                       gnorm_sq, clip, grad_scale);
+    CUTIE_CHECK_LAUNCH();
+    return CUTIE_OK;
+}
+
+extern "C" int cutie_pack_weights(const float* w_hwio, int taps, int cin, int cout, void* w_fwd, int cin_pad,
+                                  void* w_dgrad, int cout_pad, int dtype, cutie_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    CUTIE_CHECK_ARG(taps >= 1 && cin >= 1 && cout >= 1 && w_hwio, "pack_weights: bad arguments");
+    CUTIE_CHECK_ARG(!w_fwd || cin_pad >= cin, "pack_weights: cin_pad < cin");
+    CUTIE_CHECK_ARG(!w_dgrad || cout_pad >= cout, "pack_weights: cout_pad < cout");
+    const int64_t total = (w_fwd ? (int64_t)taps * cout * cin_pad : 0) + (w_dgrad ? (int64_t)taps * cin * cout_pad : 0);
+    if (total == 0) return CUTIE_OK;
+    int64_t grid = cutie::cdiv(total, 256);
+    if (grid > 4096) grid = 4096;
+    CUTIE_DISPATCH_DTYPE(dtype, DT,
+        hipLaunchKernelGGL(pack_kernel<typename elem<DT>::type>, dim3((int)grid), dim3(256), 0, stream, w_hwio, taps,
+                           cin, cout, (typename elem<DT>::type*)w_fwd, cin_pad, (typename elem<DT>::type*)w_dgrad,
+                           cout_pad));
+    CUTIE_CHECK_LAUNCH();
+    return CUTIE_OK;
+}

@@ -1,0 +1,209 @@
+"""Tensor-level wrappers over the C ABI: argument checking and pointer plumbing only.
+
+Every function launches HIP kernels on the current stream and returns device tensors.
+Activations are NHWC tensors (possibly channel-slice views of a wider concat buffer).
+"""
+import ctypes
+
+import torch
+
+from . import capi
+from .capi import BF16, F32, ConvSeg, call, dt_of, ld_of, ptr, stream
+
+IN_EPS = 1e-6  # tf.contrib.layers.instance_norm default epsilon (model_framework.py:423)
+
+
+def _bke(dt):
+    return 64 if dt == BF16 else 32
+
+
+def pad_to(c, m):
+    return (c + m - 1) // m * m
+
+
+# ------------------------------------------------------------------------------------ K0
+def grid_build(tok_box, tok_id, tok_ecid, doc_extent, doc_off, rows, cols, strategy):
+    """device int32 tensors in; dict of device tensors out (see include/cutie_hip.h K0)."""
+    dev = tok_box.device
+    B = doc_off.numel() - 1
+    T = tok_id.numel()
+    grid = torch.empty((B, rows, cols), dtype=torch.int32, device=dev)
+    labels = torch.empty((B, rows, cols), dtype=torch.int8, device=dev)
+    ps_x = torch.empty((B, rows, cols), dtype=torch.int32, device=dev)
+    ps_y = torch.empty((B, rows, cols), dtype=torch.int32, device=dev)
+    order = torch.full((max(T, 1),), -1, dtype=torch.int32, device=dev)
+    place = torch.full((max(T, 1), 2), -1, dtype=torch.int32, device=dev)
+    status = torch.zeros((max(B, 1),), dtype=torch.int32, device=dev)
+    ws_bytes = capi.lib().cutie_grid_build_workspace_bytes(T)
+    ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev)
+    call("cutie_grid_build", ptr(tok_box), ptr(tok_id), ptr(tok_ecid), ptr(doc_extent), ptr(doc_off), B, T,
+         rows, cols, strategy, ptr(grid), ptr(labels), ptr(ps_x), ptr(ps_y), ptr(order), ptr(place),
+         ptr(status), ptr(ws), ws_bytes, stream())
+    return {"grid": grid, "labels": labels, "ps_x": ps_x, "ps_y": ps_y, "order": order[:T],
+            "place": place[:T], "status": status[:B]}
+
+
+# ------------------------------------------------------------------------------------ K1
+def embed_fwd(ids, table, out, oob):
+    """ids int32 [...]; table f32 [V,E]; out [..., >=E] view; oob int32 [1] counter."""
+    V, E = table.shape
+    call("cutie_embed_fwd", ptr(ids), ids.numel(), ptr(table), V, E, ptr(out), ld_of(out), dt_of(out),
+         ptr(oob), stream())
+    return out
+
+
+def embed_bwd(ids, dout, dtable):
+    V, E = dtable.shape
+    call("cutie_embed_bwd", ptr(ids), ids.numel(), ptr(dout), ld_of(dout), dt_of(dout), ptr(dtable), V, E,
+         stream())
+    return dtable
+
+
+# ------------------------------------------------------------------------------------ K2-K5
+def pack_weights(w_hwio, dt, want_fwd=True, want_dgrad=True):
+    """f32 [kh,kw,cin,cout] -> (w_fwd [taps,cout,cin_pad], w_dgrad [taps,cin,cout_pad])."""
+    kh, kw, cin, cout = w_hwio.shape
+    tdt = capi.torch_dtype(dt)
+    cin_pad, cout_pad = pad_to(cin, _bke(dt)), pad_to(cout, _bke(dt))
+    w_fwd = torch.empty((kh * kw, cout, cin_pad), dtype=tdt, device=w_hwio.device) if want_fwd else None
+    w_dg = torch.empty((kh * kw, cin, cout_pad), dtype=tdt, device=w_hwio.device) if want_dgrad else None
+    pack_weights_into(w_hwio, dt, w_fwd, w_dg)
+    return w_fwd, w_dg
+
+
+def pack_weights_into(w_hwio, dt, w_fwd, w_dg):
+    kh, kw, cin, cout = w_hwio.shape
+    call("cutie_pack_weights", ptr(w_hwio), kh * kw, cin, cout, ptr(w_fwd),
+         w_fwd.shape[2] if w_fwd is not None else 0, ptr(w_dg), w_dg.shape[2] if w_dg is not None else 0,
+         dt, stream())
+
+
+def conv_fwd(segs, out, n_out, bias=None, relu=False, stats=None):
+    """segs: list of dict(x=[B,H,W,>=cin] view, w=packed [taps, n_rows, cin], cin, kh, kw, dil, flip,
+    n_off=row offset into w).  out: [B,H,W,>=n_out] view."""
+    B, H, W = out.shape[0], out.shape[1], out.shape[2]
+    arr = (ConvSeg * len(segs))()
+    dt = None
+    for i, s in enumerate(segs):
+        x, w = s["x"], s["w"]
+        sdt = dt_of(x)
+        if dt is None:
+            dt = sdt
+        if sdt != dt or dt_of(w) != dt:
+            raise capi.CutieError("conv_fwd: segment dtypes differ")
+        if x.shape[0] != B or x.shape[1] != H or x.shape[2] != W:
+            raise capi.CutieError("conv_fwd: segment %d spatial shape %s != out %s" % (i, tuple(x.shape), tuple(out.shape)))
+        cin = s["cin"]
+        if w.shape[2] != cin or x.shape[3] < cin and ld_of(x) < cin:
+            raise capi.CutieError("conv_fwd: segment %d cin=%d, w %s, x %s" % (i, cin, tuple(w.shape), tuple(x.shape)))
+        n_off = s.get("n_off", 0)
+        if n_off + n_out > w.shape[1] or w.shape[0] != s["kh"] * s["kw"]:
+            raise capi.CutieError("conv_fwd: segment %d weight rows %d < %d+%d" % (i, w.shape[1], n_off, n_out))
+        arr[i].x = ptr(x)
+        arr[i].w = ptr(w) + n_off * cin * w.element_size()
+        arr[i].w_tap_stride = w.shape[1] * w.shape[2]
+        arr[i].ld_x = ld_of(x)
+        arr[i].cin = cin
+        arr[i].kh, arr[i].kw, arr[i].dil = s["kh"], s["kw"], s["dil"]
+        arr[i].flip = 1 if s.get("flip") else 0
+    call("cutie_conv_fwd", arr, len(segs), B, H, W, n_out, ptr(out), ld_of(out), dt_of(out), ptr(bias),
+         1 if relu else 0, ptr(stats), dt, stream())
+    return out
+
+
+def conv_wgrad_workspace_bytes(B, H, W, cin, cout, kh, kw):
+    return capi.lib().cutie_conv_wgrad_workspace_bytes(B, H, W, cin, cout, kh, kw)
+
+
+def conv_wgrad(x, cin, dz, cout, kh, kw, dil, dw, workspace, accumulate=False):
+    """dw f32 [kh,kw,cin,cout] (HWIO); x/dz NHWC views; workspace uint8 tensor."""
+    B, H, W = dz.shape[0], dz.shape[1], dz.shape[2]
+    call("cutie_conv_wgrad", ptr(x), ld_of(x), cin, ptr(dz), ld_of(dz), cout, B, H, W, kh, kw, dil, ptr(dw),
+         1 if accumulate else 0, dt_of(x), ptr(workspace), workspace.numel() * workspace.element_size(), stream())
+    return dw
+
+
+# ------------------------------------------------------------------------------------ K6, K8
+def _bhwc(t):
+    return t.shape[0], t.shape[1] * t.shape[2], t.shape[3]
+
+
+def in_stats(a, stats):
+    B, HW, C = _bhwc(a)
+    call("cutie_in_stats", ptr(a), ld_of(a), dt_of(a), B, HW, C, ptr(stats), stream())
+    return stats
+
+
+def in_apply(a, stats, y, eps=IN_EPS):
+    B, HW, C = _bhwc(a)
+    call("cutie_in_apply", ptr(a), ld_of(a), dt_of(a), ptr(stats), eps, ptr(y), ld_of(y), dt_of(y), B, HW, C,
+         stream())
+    return y
+
+
+def in_bwd_stats(dy, a, stats, red, eps=IN_EPS):
+    B, HW, C = _bhwc(a)
+    call("cutie_in_bwd_stats", ptr(dy), ld_of(dy), dt_of(dy), ptr(a), ld_of(a), dt_of(a), ptr(stats), eps,
+         ptr(red), B, HW, C, stream())
+    return red
+
+
+def in_bwd_apply(dy, a, stats, red, dz, dbias=None, relu=True, eps=IN_EPS):
+    B, HW, C = _bhwc(a)
+    call("cutie_in_bwd_apply", ptr(dy), ld_of(dy), dt_of(dy), ptr(a), ld_of(a), dt_of(a), ptr(stats), eps,
+         ptr(red), 1 if relu else 0, ptr(dz), ld_of(dz), dt_of(dz), ptr(dbias), B, HW, C, stream())
+    return dz
+
+
+def spatial_mean_bcast(x, out):
+    B, HW, C = _bhwc(x)
+    call("cutie_spatial_mean_bcast", ptr(x), ld_of(x), dt_of(x), ptr(out), ld_of(out), dt_of(out), B, HW, C,
+         stream())
+    return out
+
+
+# ------------------------------------------------------------------------------------ K9-K11
+def softmax_ce_fwd(logits, labels, C, ce, probs, bad):
+    """logits [..., >=C] view; labels int32 [...]; ce f32 [N]; probs f32 [N,C] or None."""
+    n = labels.numel()
+    call("cutie_softmax_ce_fwd", ptr(logits), ld_of(logits), dt_of(logits), ptr(labels), n, C, ptr(ce),
+         ptr(probs), ptr(bad), stream())
+
+
+def hnm_weights(ce, labels, ratio, weight, loss_out):
+    call("cutie_hnm_weights", ptr(ce), ptr(labels), labels.numel(), int(ratio), ptr(weight), ptr(loss_out),
+         None, 0, stream())
+
+
+def softmax_ce_bwd(probs, labels, weight, C, dlogits):
+    call("cutie_softmax_ce_bwd", ptr(probs), ptr(labels), ptr(weight), labels.numel(), C, ptr(dlogits),
+         ld_of(dlogits), dt_of(dlogits), stream())
+
+
+# ------------------------------------------------------------------------------------ K12, K14
+def l2_add(w, g, wd, reg_loss, scratch):
+    call("cutie_l2_add", ptr(w), ptr(g), w.numel(), float(wd), ptr(reg_loss), ptr(scratch), stream())
+
+
+def sumsq(x, out, scratch):
+    call("cutie_sumsq", ptr(x), x.numel(), dt_of(x), ptr(out), ptr(scratch), stream())
+
+
+def adam_step(p, g, m, v, lr_t, beta1, beta2, eps, gnorm_sq, clip, grad_scale=1.0):
+    call("cutie_adam_step", ptr(p), ptr(g), ptr(m), ptr(v), p.numel(), float(lr_t), float(beta1), float(beta2),
+         float(eps), ptr(gnorm_sq), float(clip), float(grad_scale), stream())
+
+
+def batch_gather(feat, idx, out):
+    """feat [B, n_src, C]; idx int32 [B, n_cells]; out [B, n_cells, >=C] view."""
+    B, n_src, C = feat.shape
+    call("cutie_batch_gather", ptr(feat), ld_of(feat), n_src, ptr(idx), idx.shape[1], B, C, ptr(out), ld_of(out),
+         dt_of(feat), stream())
+    return out
+
+
+def convert(src, dst):
+    C = src.shape[-1]
+    n_rows = src.numel() // C
+    call("cutie_convert", ptr(src), ld_of(src), dt_of(src), ptr(dst), ld_of(dst), dt_of(dst), n_rows, C, stream())
+    return dst

@@ -1,0 +1,221 @@
+/* cutie_hip.h - C ABI of libcutie_hip.so: the MI355X (gfx950) kernels behind CUTIE's hot path.
+ *
+ * The reference (vsymbol/CUTIE, TensorFlow 1.12) has no FFI: its boundary is the Python API
+ * between the drivers and model_framework.Model / DataLoader.  The
+ * Python mirror of that API lives in cutie_amd/ and calls the entry points below through
+ * ctypes.  Each entry point cites the reference call site whose arithmetic it replaces
+ * (paths relative to /root/reference).
+ *
+ * Conventions
+ *   - every function returns 0 on success or a negative CUTIE_E_* code; the message of the
+ *     last failure on the calling thread is cutie_last_error().  Nothing throws or aborts.
+ *   - the caller owns every buffer (device pointers unless marked "host"); functions that
+ *     need scratch take a workspace and publish its size through *_workspace_bytes().
+ *   - every launch goes to the hipStream_t passed in (as void*), asynchronously.
+ *   - activations are NHWC with an explicit leading dimension: element (b,h,w,c) of a view
+ *     lives at base[((b*H + h)*W + w)*ld + c]; a concat is a wider buffer whose producers
+ *     write channel slices (model_framework.py:294-296 needs no kernel).
+ *   - dtype: CUTIE_F32 or CUTIE_BF16 activations; statistics, losses, parameters and
+ *     gradients are always f32; ids/labels are int32 (labels in the grid are int8).
+ */
+#ifndef CUTIE_HIP_H
+#define CUTIE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CUTIE_F32 0
+#define CUTIE_BF16 1
+
+#define CUTIE_OK 0
+#define CUTIE_E_ARG (-1)      /* bad shape / pointer / alignment / unsupported option */
+#define CUTIE_E_HIP (-2)      /* a HIP runtime call failed */
+#define CUTIE_E_WORKSPACE (-3)/* workspace too small */
+
+#define CUTIE_MAX_SEGS 6
+
+typedef void* cutie_stream_t; /* hipStream_t */
+
+int cutie_version(void);
+const char* cutie_last_error(void);
+
+/* ---------------------------------------------------------------------------------------
+ * K0  token -> grid positional mapping.   Replaces DataLoader._positional_mapping,
+ *     data_loader_json.py:437-577 (strategies 0 and 1; bit-exact, fp64 keys, stable order).
+ *
+ * tok_box    int32 [T,4]  x_left,y_top,x_right,y_bottom per token, documents concatenated
+ * tok_id     int32 [T]    dict id (word_to_index[text], :469)
+ * tok_ecid   int32 [T]    entity_id*num_classes + class_id (:510)
+ * doc_extent int32 [B,4]  left,top,right,bottom of the document (:467)
+ * doc_off    int32 [B+1]  token range of document b is [doc_off[b], doc_off[b+1])
+ * outputs    grid int32 [B,rows,cols], labels int8 [B,rows,cols], ps_x/ps_y int32 [B,rows,cols]
+ *            tok_order int32 [T]: for document b, tok_order[doc_off[b]+k] = index (within the
+ *                 document) of the k-th token in placement order (the stable sort of :507)
+ *            tok_place int32 [T,2]: (row,col) where that k-th token was written, (-1,-1) if
+ *                 strategy 0 dropped it
+ *            status int32 [B]: 0 ok; 1 = some token maps outside the grid (the reference
+ *                 raises IndexError or writes into its cropped buffer half); outputs of such
+ *                 a document are unspecified.
+ * workspace  cutie_grid_build_workspace_bytes(T) bytes.
+ * limits     rows*cols*4 bytes must fit the 160 KB LDS (<= 36864 cells), rows <= 1024.
+ */
+size_t cutie_grid_build_workspace_bytes(int n_tokens);
+int cutie_grid_build(const int32_t* tok_box, const int32_t* tok_id, const int32_t* tok_ecid,
+                     const int32_t* doc_extent, const int32_t* doc_off, int n_docs, int n_tokens,
+                     int rows, int cols, int strategy,
+                     int32_t* grid, int8_t* labels, int32_t* ps_x, int32_t* ps_y,
+                     int32_t* tok_order, int32_t* tok_place, int32_t* status,
+                     void* workspace, size_t workspace_bytes, cutie_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------
+ * K1  embedding gather.   Replaces tf.nn.embedding_lookup in Model.embed,
+ *     model_framework.py:43-54 (dropout keep_prob 1 is the identity).
+ * out[cell, 0:E] = table[ids[cell], 0:E].  An id outside [0,V) gives a zero row and bumps
+ * *oob_count (int32, caller-zeroed) - TF's GPU gather returns zeros, its CPU gather raises.
+ * E must be a multiple of 4.
+ */
+int cutie_embed_fwd(const int32_t* ids, int64_t n_cells, const float* table, int V, int E,
+                    void* out, int ld_out, int out_dtype, int32_t* oob_count,
+                    cutie_stream_t stream);
+
+/* backward of K1: dtable[ids[cell], :] += dout[cell, :]  (f32 accumulate; dtable is NOT
+ * cleared here).  This is the scatter-add TF applies to the IndexedSlices gradient.
+ * Ids 0 and 1 ([PAD] = empty cell, [UNK]) are pre-reduced per workgroup before the atomics. */
+int cutie_embed_bwd(const int32_t* ids, int64_t n_cells, const void* dout, int ld_dout,
+                    int dout_dtype, float* dtable, int V, int E, cutie_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------
+ * K2-K5  stride-1 SAME (dilated) cross-correlation as an implicit GEMM on MFMA, with the
+ *     bias + ReLU epilogue and the instance-norm statistics.   Replaces tf.nn.conv2d /
+ *     tf.nn.atrous_conv2d + bias_add + relu in Model.conv / dilate_conv / convolution,
+ *     model_framework.py:168-204,414-422, and their tf.gradients data-gradient.
+ *
+ * out[b,h,w,n] = act( bias[n] + sum over segments s, taps (i,j), channels c of
+ *        x_s[b, h + sgn_s*(i - kh_s/2)*dil_s, w + sgn_s*(j - kw_s/2)*dil_s, c] * w_s[(i*kw_s+j)][n][c] )
+ * with zero padding, sgn = +1 (forward) or -1 (flip != 0: the data gradient, fed with the
+ * layer's output gradient and weights packed [tap][cin][cout]).  Several segments give the
+ * gradient of a tensor with several consumers in one pass (no read-modify-write).
+ * stats (nullable) f32 [B][n_out][2]: += sum and sum of squares over (h,w) of the values
+ * stored (caller-zeroed) - the instance-norm moments of model_framework.py:423.
+ */
+typedef struct {
+    const void* x;        /* activations view, dtype of the call                          */
+    const void* w;        /* packed weights [kh*kw][n rows][cin] in the call's dtype       */
+    int64_t w_tap_stride; /* elements between taps (n_total*cin of the packed tensor)      */
+    int ld_x;             /* leading dimension of x in elements                            */
+    int cin;              /* channels contracted; multiple of 32 (f32) / 64 (bf16) - pad   */
+    int kh, kw, dil;
+    int flip;             /* 0 forward taps, 1 negated shifts (data gradient)              */
+} cutie_conv_seg;
+
+int cutie_conv_fwd(const cutie_conv_seg* segs /* host */, int n_segs,
+                   int B, int H, int W, int n_out,
+                   void* out, int ld_out, int out_dtype,
+                   const float* bias, int relu, float* stats,
+                   int dtype, cutie_stream_t stream);
+
+/* weight gradient: dw[(i*kw+j)][c][n] (= HWIO, model_framework.py:416) =
+ *   sum over b,h,w of x[b, h+(i-kh/2)*dil, w+(j-kw/2)*dil, c] * dz[b,h,w,n].
+ * Deterministic: K is split over `splits` row groups into f32 slabs in the workspace, then
+ * summed in a fixed order; `accumulate` != 0 adds into dw instead of overwriting. */
+size_t cutie_conv_wgrad_workspace_bytes(int B, int H, int W, int cin, int cout, int kh, int kw);
+int cutie_conv_wgrad(const void* x, int ld_x, int cin, const void* dz, int ld_dz, int cout,
+                     int B, int H, int W, int kh, int kw, int dil,
+                     float* dw, int accumulate, int dtype,
+                     void* workspace, size_t workspace_bytes, cutie_stream_t stream);
+
+/* packs f32 HWIO weights [kh*kw][cin][cout] (the layout of '<layer>/weights') into the two
+ * operand layouts the conv kernels read: w_fwd [tap][cout][cin_pad] and w_dgrad
+ * [tap][cin][cout_pad] (either may be NULL), zero padded, in `dtype`. */
+int cutie_pack_weights(const float* w_hwio, int taps, int cin, int cout,
+                       void* w_fwd, int cin_pad, void* w_dgrad, int cout_pad,
+                       int dtype, cutie_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------
+ * K6  instance norm, center=False scale=False, eps 1e-6, biased variance.   Replaces
+ *     tf.contrib.layers.instance_norm at model_framework.py:423 and its gradient.
+ * stats f32 [B][C][2] = (sum, sum of squares) over H*W as produced by cutie_conv_fwd.
+ *   apply:     y = (a - mean) * rsqrt(var + eps)
+ *   bwd_stats: red[b][c] = (sum dy, sum dy*xhat)           (caller-zeroed, f32 [B][C][2])
+ *   bwd_apply: dz = [a > 0] * inv * (dy - red0/HW - xhat*red1/HW);  dbias[c] += sum dz
+ *              (relu != 0 applies the ReLU mask of model_framework.py:173; dbias nullable)
+ */
+int cutie_in_stats(const void* a, int ld_a, int a_dtype, int B, int HW, int C, float* stats,
+                   cutie_stream_t stream);
+int cutie_in_apply(const void* a, int ld_a, int a_dtype, const float* stats, float eps,
+                   void* y, int ld_y, int y_dtype, int B, int HW, int C, cutie_stream_t stream);
+int cutie_in_bwd_stats(const void* dy, int ld_dy, int dy_dtype, const void* a, int ld_a,
+                       int a_dtype, const float* stats, float eps, float* red,
+                       int B, int HW, int C, cutie_stream_t stream);
+int cutie_in_bwd_apply(const void* dy, int ld_dy, int dy_dtype, const void* a, int ld_a,
+                       int a_dtype, const float* stats, float eps, const float* red, int relu,
+                       void* dz, int ld_dz, int dz_dtype, float* dbias,
+                       int B, int HW, int C, cutie_stream_t stream);
+
+/* K8  Model.global_pool, model_framework.py:309-315: spatial mean broadcast back to HxW
+ * (reduce_mean + nearest-neighbour resize), written into a channel slice. */
+int cutie_spatial_mean_bcast(const void* x, int ld_x, int x_dtype, void* out, int ld_out,
+                             int out_dtype, int B, int HW, int C, cutie_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------
+ * K9-K11  per-cell softmax cross-entropy with hard negative mining.   Replaces
+ *     Model.softmax (model_framework.py:318-320) and CUTIE.build_loss
+ *     (model_cutie.py:107-130; duplicate at model_cutie2.py:114-147).
+ * fwd:    probs[n,:] = softmax(logits[n,:]) (nullable), ce[n] = logsumexp - logits[n,label]
+ *         a label outside [0,C) bumps *bad_labels (caller-zeroed) and gives ce = NaN.
+ * hnm:    Nfg = #{label != 0}, num_bg = min(Nbg, ratio*Nfg); selects the num_bg largest
+ *         background ce (ties: lower index first, as tf.nn.top_k); weight[n] = 1/Nfg (fg),
+ *         1/num_bg (selected bg), 0 otherwise;  loss_out[0] = mean(fg ce) + mean(selected)
+ *         (NaN when either set is empty, as reduce_mean of an empty tensor), loss_out[1] =
+ *         Nfg, loss_out[2] = num_bg.  Single workgroup; workspace >= hnm_workspace_bytes.
+ * bwd:    dlogits[n,c] = weight[n] * (probs[n,c] - [c == label[n]])
+ */
+int cutie_softmax_ce_fwd(const void* logits, int ld, int dtype, const int32_t* labels,
+                         int64_t n_cells, int C, float* ce, float* probs,
+                         int32_t* bad_labels, cutie_stream_t stream);
+size_t cutie_hnm_workspace_bytes(int64_t n_cells);
+int cutie_hnm_weights(const float* ce, const int32_t* labels, int64_t n_cells, int ratio,
+                      float* weight, float* loss_out, void* workspace, size_t workspace_bytes,
+                      cutie_stream_t stream);
+int cutie_softmax_ce_bwd(const float* probs, const int32_t* labels, const float* weight,
+                         int64_t n_cells, int C, void* dlogits, int ld, int dtype,
+                         cutie_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------
+ * K12,K14  L2 regulariser, global-norm clip and Adam over flat f32 buffers.   Replaces
+ *     l2_regularizer (model_framework.py:427-432), tf.clip_by_global_norm(.., 10.0) and
+ *     tf.train.AdamOptimizer.apply_gradients (main_train_json.py:152-156).
+ * l2:    g += wd * w;  *reg_loss += wd * sum(w^2)/2            (reg_loss caller-zeroed)
+ * sumsq: *out += sum(x^2)                                       (out caller-zeroed)
+ *        both reduce in two stages over a fixed grid through `scratch` (CUTIE_REDUCE_SCRATCH
+ *        floats, clobbered) in a fixed order: bit-identical on every data-parallel replica.
+ * adam:  scale = clip / max(sqrt(*gnorm_sq), clip);  g' = g*scale;
+ *        m = b1*m + (1-b1)*g';  v = b2*v + (1-b2)*g'^2;  p -= lr_t * m / (sqrt(v) + eps)
+ *        with lr_t = lr*sqrt(1-b2^t)/(1-b1^t) computed by the caller (TF's form).
+ */
+#define CUTIE_REDUCE_SCRATCH 1024 /* floats of caller scratch for the two-stage reductions */
+int cutie_l2_add(const float* w, float* g, int64_t n, float wd, float* reg_loss, float* scratch,
+                 cutie_stream_t stream);
+int cutie_sumsq(const void* x, int64_t n, int dtype, float* out, float* scratch,
+                cutie_stream_t stream);
+int cutie_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr_t,
+                    float beta1, float beta2, float eps, const float* gnorm_sq, float clip,
+                    float grad_scale, cutie_stream_t stream);
+
+/* K13  Model.positional_sampling, model_framework.py:73-86 (tf.batch_gather):
+ * out[b, cell, :] = feat[b, idx[b, cell], :], idx clamped to [0, n_src). */
+int cutie_batch_gather(const void* feat, int ld_feat, int n_src, const int32_t* idx, int n_cells,
+                       int B, int C, void* out, int ld_out, int dtype, cutie_stream_t stream);
+
+/* dtype conversion of a [n_rows, C] view (used for the image input and f32 <-> bf16 views) */
+int cutie_convert(const void* src, int ld_src, int src_dtype, void* dst, int ld_dst,
+                  int dst_dtype, int64_t n_rows, int C, cutie_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CUTIE_HIP_H */

@@ -1,0 +1,434 @@
+"""GPU parity tests, kernel by kernel, through the C ABI (cutie_amd.ops -> libcutie_hip.so).
+
+Checker: oracle/ (CPU restatements; grid oracle pinned to the reference's golden vectors,
+model ops on PyTorch CPU float64) and tests/golden fixtures.  Bars: integer / index work
+bit-exact; f32 path 1e-4 relative to the tensor's max magnitude; bf16 path 2e-2 (inputs are
+rounded to bf16 before both sides see them, so only accumulation/rounding differs).
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import cutie_oracle as co  # noqa: E402
+from oracle import grid_oracle as go  # noqa: E402
+
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def ops():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from cutie_amd import ops as _ops
+    return _ops
+
+
+def relerr(got, ref):
+    got = got.detach().double().cpu()
+    ref = ref.detach().double().cpu()
+    return float((got - ref).abs().max() / ref.abs().max().clamp_min(1e-30))
+
+
+def pack_docs(docs):
+    box, ids, ecid, ext, off = [], [], [], [], [0]
+    return box, ids, ecid, ext, off
+
+
+def run_grid(ops, docs, rows, cols, strategy, num_classes):
+    box, ids, ecid, ext, off = [], [], [], [], [0]
+    for d in docs:
+        for t in d:
+            box.append(t["box"])
+            ids.append(t["dict_id"])
+            ecid.append(t["entity_id"] * num_classes + t["class_id"])
+        ext.append(d[0]["extent"] if d else [0, 0, 1, 1])
+        off.append(len(ids))
+    ti = lambda a, shape: torch.tensor(a, dtype=torch.int32).reshape(shape).to(DEV)
+    out = ops.grid_build(ti(box, (-1, 4)), ti(ids, (-1,)), ti(ecid, (-1,)), ti(ext, (-1, 4)), ti(off, (-1,)),
+                         rows, cols, strategy)
+    torch.cuda.synchronize()
+    return {k: v.cpu().numpy() for k, v in out.items()}, off
+
+
+# ------------------------------------------------------------------------------------ K0
+def test_grid_build_faktura_golden(ops, golden_dir):
+    with open(os.path.join(golden_dir, "faktura1_items.json"), encoding="utf-8") as f:
+        items = json.load(f)
+    with open(os.path.join(golden_dir, "faktura1_grids.json")) as f:
+        meta = json.load(f)
+    npz = np.load(os.path.join(golden_dir, "faktura1_grids.npz"))
+    doc = items["docs"]["training"][0]
+    nc = items["num_classes"]
+    n = 0
+    for key, m in meta.items():
+        if "error" in m:
+            continue
+        out, off = run_grid(ops, [doc], m["rows"], m["cols"], m["strategy"], nc)
+        assert out["status"].tolist() == [0], key
+        np.testing.assert_array_equal(out["grid"], npz[key + "_grid"][..., 0], err_msg=key)
+        np.testing.assert_array_equal(out["labels"], npz[key + "_labels"], err_msg=key)
+        if m["strategy"] == 1:
+            np.testing.assert_array_equal(out["ps_x"], npz[key + "_ps_x"], err_msg=key)
+            np.testing.assert_array_equal(out["ps_y"], npz[key + "_ps_y"], err_msg=key)
+        ref = go.positional_mapping([doc], m["rows"], m["cols"], m["strategy"], nc)
+        assert out["order"].tolist() == ref["order"][0], key
+        assert [tuple(p) for p in out["place"].tolist()] == ref["placed"][0], key
+        n += 1
+    assert n >= 12
+
+
+def test_grid_build_synthetic_golden(ops, golden_dir):
+    with open(os.path.join(golden_dir, "synthetic_grids.json")) as f:
+        meta = json.load(f)
+    npz = np.load(os.path.join(golden_dir, "synthetic_grids.npz"))
+    nc = meta["num_classes"]
+    for case in meta["cases"]:
+        name = case["name"]
+        out, off = run_grid(ops, case["docs"], case["rows"], case["cols"], case["strategy"], nc)
+        assert not out["status"].any(), name
+        np.testing.assert_array_equal(out["grid"], npz[name + "_grid"][..., 0], err_msg=name)
+        np.testing.assert_array_equal(out["labels"], npz[name + "_labels"], err_msg=name)
+        if case["strategy"] == 1:
+            np.testing.assert_array_equal(out["ps_x"], npz[name + "_ps_x"], err_msg=name)
+            np.testing.assert_array_equal(out["ps_y"], npz[name + "_ps_y"], err_msg=name)
+        ref = go.positional_mapping(case["docs"], case["rows"], case["cols"], case["strategy"], nc)
+        for d in range(len(case["docs"])):
+            assert out["order"][off[d]:off[d + 1]].tolist() == ref["order"][d], name
+            assert [tuple(p) for p in out["place"][off[d]:off[d + 1]].tolist()] == ref["placed"][d], name
+
+
+def test_grid_build_edges(ops):
+    # empty batch entry, out-of-grid token -> status 1, large grid 256x128
+    tok = {"box": [10, 10, 30, 20], "extent": [8, 8, 100, 100], "dict_id": 7, "class_id": 2, "entity_id": 0}
+    bad = {"box": [0, 0, 10, 10], "extent": [0, 0, 5, 5], "dict_id": 3, "class_id": 0, "entity_id": 0}
+    out, _ = run_grid(ops, [[tok], [bad], [tok, tok]], 256, 128, 1, 18)
+    assert out["status"].tolist() == [0, 1, 0]
+    ref = go.positional_mapping([[tok], [tok, tok]], 256, 128, 1, 18)
+    np.testing.assert_array_equal(out["grid"][0], ref["grid"][0])
+    np.testing.assert_array_equal(out["grid"][2], ref["grid"][1])
+    np.testing.assert_array_equal(out["labels"][2], ref["labels"][1])
+
+
+# ------------------------------------------------------------------------------------ K1
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+def test_embed_fwd_bwd(ops, dt):
+    g = torch.Generator().manual_seed(1)
+    V, E, n = 300, 128, 5000
+    tdt = torch.float32 if dt == "f32" else torch.bfloat16
+    table = torch.rand((V, E), generator=g) * 2 - 1
+    ids = torch.randint(0, V, (n,), generator=g, dtype=torch.int32)
+    ids[torch.rand(n, generator=g) < 0.6] = 0
+    ids[torch.rand(n, generator=g) < 0.1] = 1
+    ids[17] = V + 5      # out of range -> zero row + counter
+    ids[18] = -1
+    out = torch.full((n, E + 64), 7.0, dtype=tdt, device=DEV)
+    oob = torch.zeros(1, dtype=torch.int32, device=DEV)
+    ops.embed_fwd(ids.to(DEV), table.to(DEV), out[:, :E], oob)
+    ref = table[ids.clamp(0, V - 1).long()].clone()
+    ref[17] = 0
+    ref[18] = 0
+    assert int(oob.item()) == 2
+    got = out[:, :E].float().cpu()
+    if dt == "f32":
+        assert torch.equal(got, ref)
+    else:
+        assert torch.equal(got, ref.bfloat16().float())
+    assert torch.all(out[:, E:] == 7.0)
+    # backward: scatter-add
+    dout = (torch.randn((n, E), generator=g)).to(tdt)
+    dtab = torch.zeros((V, E), dtype=torch.float32, device=DEV)
+    ops.embed_bwd(ids.to(DEV), dout.to(DEV), dtab)
+    valid = (ids >= 0) & (ids < V)
+    refg = torch.zeros((V, E), dtype=torch.float64)
+    refg.index_add_(0, ids[valid].long(), dout[valid].double())
+    assert relerr(dtab, refg) < 1e-5
+
+
+# ------------------------------------------------------------------------------------ K2-K5
+def _rand_act(g, shape, tdt):
+    return (torch.randn(shape, generator=g) * 0.7).to(tdt)
+
+
+CONV_CASES = [
+    # B, H, W, cin, cout, kh, kw, dil
+    (2, 20, 64, 64, 128, 3, 5, 1),
+    (1, 40, 64, 128, 96, 3, 5, 2),
+    (1, 20, 64, 64, 128, 3, 5, 4),
+    (1, 24, 64, 64, 64, 3, 5, 8),
+    (1, 40, 64, 64, 256, 3, 5, 16),
+    (2, 9, 40, 64, 18, 1, 1, 1),
+    (1, 7, 80, 64, 160, 3, 5, 2),
+    (1, 5, 130, 64, 64, 3, 5, 1),
+    (1, 12, 12, 64, 64, 3, 5, 1),
+    (1, 6, 128, 64, 32, 3, 3, 2),
+]
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv_fwd(ops, dt, case):
+    from cutie_amd import capi
+    B, H, W, cin, cout, kh, kw, dil = case
+    g = torch.Generator().manual_seed(hash(case) % 1000)
+    tdt = torch.float32 if dt == "f32" else torch.bfloat16
+    cdt = capi.F32 if dt == "f32" else capi.BF16
+    x = _rand_act(g, (B, H, W, cin), tdt)
+    w = (torch.randn((kh, kw, cin, cout), generator=g) * 0.05).to(tdt).float()
+    bias = torch.randn(cout, generator=g) * 0.1
+    ref_z = co.conv_raw(x.double(), w.double(), dil) + bias.double()
+    ref_a = torch.relu(ref_z)
+    wf, _ = ops.pack_weights(w.to(DEV), cdt)
+    ld_out = cout + 8
+    out = torch.full((B, H, W, ld_out), 3.0, dtype=torch.float32, device=DEV)
+    stats = torch.zeros((B, cout, 2), dtype=torch.float32, device=DEV)
+    xd = torch.zeros((B, H, W, cin + 64), dtype=tdt, device=DEV)   # read through a channel-slice view
+    xd[..., 32:32 + cin] = x.to(DEV)
+    ops.conv_fwd([dict(x=xd[..., 32:32 + cin], w=wf, cin=cin, kh=kh, kw=kw, dil=dil)], out[..., :cout], cout,
+                 bias=bias.to(DEV), relu=True, stats=stats)
+    torch.cuda.synchronize()
+    tol = 1e-4 if dt == "f32" else 2e-3      # f32 accumulate of bf16 products; inputs identical
+    assert relerr(out[..., :cout], ref_a) < tol
+    assert torch.all(out[..., cout:] == 3.0)
+    ref_s = torch.stack([ref_a.sum(dim=(1, 2)), (ref_a ** 2).sum(dim=(1, 2))], dim=-1)
+    assert relerr(stats, ref_s) < (1e-4 if dt == "f32" else 2e-3)
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+def test_conv_bf16_out_and_no_relu(ops, dt):
+    from cutie_amd import capi
+    B, H, W, cin, cout, kh, kw, dil = 1, 16, 64, 64, 128, 3, 5, 2
+    g = torch.Generator().manual_seed(5)
+    tdt = torch.float32 if dt == "f32" else torch.bfloat16
+    cdt = capi.F32 if dt == "f32" else capi.BF16
+    x = _rand_act(g, (B, H, W, cin), tdt)
+    w = (torch.randn((kh, kw, cin, cout), generator=g) * 0.05).to(tdt).float()
+    ref = co.conv_raw(x.double(), w.double(), dil)
+    wf, _ = ops.pack_weights(w.to(DEV), cdt)
+    out = torch.zeros((B, H, W, cout), dtype=torch.bfloat16, device=DEV)
+    ops.conv_fwd([dict(x=x.to(DEV), w=wf, cin=cin, kh=kh, kw=kw, dil=dil)], out, cout)
+    assert relerr(out, ref) < 6e-3     # one bf16 rounding of the output
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+def test_conv_dgrad_multi_segment(ops, dt):
+    """d(loss)/dx of a tensor consumed by two convs (3x5 dil 2 with 128 outputs, and channels
+    [0:64) of a 3x5 dil 1 conv over a 128-channel concat with 64 outputs) in ONE launch."""
+    from cutie_amd import capi
+    g = torch.Generator().manual_seed(9)
+    tdt = torch.float32 if dt == "f32" else torch.bfloat16
+    cdt = capi.F32 if dt == "f32" else capi.BF16
+    B, H, W, C = 2, 12, 64, 64
+    w1 = (torch.randn((3, 5, C, 128), generator=g) * 0.05).to(tdt).float()
+    w2 = (torch.randn((3, 5, 128, 64), generator=g) * 0.05).to(tdt).float()
+    dz1 = _rand_act(g, (B, H, W, 128), tdt)
+    dz2 = _rand_act(g, (B, H, W, 64), tdt)
+    x = torch.zeros((B, H, W, C), dtype=torch.float64, requires_grad=True)
+    other = torch.zeros((B, H, W, 64), dtype=torch.float64)
+    y1 = co.conv_raw(x, w1.double(), 2)
+    y2 = co.conv_raw(torch.cat([x, other], dim=3), w2.double(), 1)
+    ((y1 * dz1.double()).sum() + (y2 * dz2.double()).sum()).backward()
+    _, wd1 = ops.pack_weights(w1.to(DEV), cdt, want_fwd=False)
+    _, wd2 = ops.pack_weights(w2.to(DEV), cdt, want_fwd=False)
+    out = torch.zeros((B, H, W, C), dtype=torch.float32, device=DEV)
+    ops.conv_fwd([dict(x=dz1.to(DEV), w=wd1, cin=128, kh=3, kw=5, dil=2, flip=True),
+                  dict(x=dz2.to(DEV), w=wd2, cin=64, kh=3, kw=5, dil=1, flip=True, n_off=0)], out, C)
+    assert relerr(out, x.grad) < (1e-4 if dt == "f32" else 2e-3)
+
+
+WGRAD_CASES = [
+    (2, 10, 64, 64, 128, 3, 5, 1),
+    (1, 40, 64, 128, 64, 3, 5, 16),
+    (3, 6, 40, 64, 18, 1, 1, 1),
+    (1, 9, 80, 96, 72, 3, 5, 2),
+    (1, 5, 130, 64, 64, 3, 3, 4),
+]
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+@pytest.mark.parametrize("case", WGRAD_CASES)
+def test_conv_wgrad(ops, dt, case):
+    B, H, W, cin, cout, kh, kw, dil = case
+    g = torch.Generator().manual_seed(hash(case) % 1000 + 1)
+    tdt = torch.float32 if dt == "f32" else torch.bfloat16
+    x = _rand_act(g, (B, H, W, cin), tdt)
+    dz = _rand_act(g, (B, H, W, cout), tdt)
+    w = torch.zeros((kh, kw, cin, cout), dtype=torch.float64, requires_grad=True)
+    (co.conv_raw(x.double(), w, dil) * dz.double()).sum().backward()
+    ldz = (cout + 7) // 8 * 8
+    dzd = torch.zeros((B, H, W, ldz), dtype=tdt, device=DEV)
+    dzd[..., :cout] = dz.to(DEV)
+    dw = torch.full((kh, kw, cin, cout), 9.0, dtype=torch.float32, device=DEV)
+    ws = torch.empty(ops.conv_wgrad_workspace_bytes(B, H, W, cin, cout, kh, kw), dtype=torch.uint8, device=DEV)
+    ops.conv_wgrad(x.to(DEV), cin, dzd[..., :cout], cout, kh, kw, dil, dw, ws)
+    assert relerr(dw, w.grad) < (1e-4 if dt == "f32" else 2e-3)
+    ops.conv_wgrad(x.to(DEV), cin, dzd[..., :cout], cout, kh, kw, dil, dw, ws, accumulate=True)
+    assert relerr(dw, 2 * w.grad) < (1e-4 if dt == "f32" else 2e-3)
+
+
+# ------------------------------------------------------------------------------------ K6, K8
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+@pytest.mark.parametrize("C", [256, 64, 18])
+def test_instance_norm_fwd_bwd(ops, dt, C):
+    g = torch.Generator().manual_seed(3)
+    tdt = torch.float32 if dt == "f32" else torch.bfloat16
+    B, H, W = 2, 20, 24
+    a = torch.relu(torch.randn((B, H, W, C), generator=g) + 0.3).to(tdt)
+    a[0, :, :, 1] = 0     # all-zero channel -> y = 0
+    dy = torch.randn((B, H, W, C), generator=g).to(tdt)
+    a64 = a.double().requires_grad_(True)
+    # relu is the identity on a >= 0 with mask [a > 0]
+    pre = a64
+    y_ref = co.instance_norm(pre)
+    ld = (C + 3) // 4 * 4 + 4
+    ad = torch.zeros((B, H, W, ld), dtype=tdt, device=DEV)
+    ad[..., :C] = a.to(DEV)
+    stats = torch.zeros((B, C, 2), dtype=torch.float32, device=DEV)
+    ops.in_stats(ad[..., :C], stats)
+    ref_s = torch.stack([a.double().sum(dim=(1, 2)), (a.double() ** 2).sum(dim=(1, 2))], dim=-1)
+    assert relerr(stats, ref_s) < 1e-5
+    y = torch.full((B, H, W, ld), 5.0, dtype=torch.float32, device=DEV)
+    ops.in_apply(ad[..., :C], stats, y[..., :C])
+    assert relerr(y[..., :C], y_ref) < 1e-4
+    assert torch.all(y[..., C:] == 5.0)
+    assert float(y[0, :, :, 1].abs().max()) == 0.0
+    # backward through IN and the ReLU mask
+    (y_ref * dy.double()).sum().backward()
+    da_ref = a64.grad * (a.double() > 0)
+    red = torch.zeros((B, C, 2), dtype=torch.float32, device=DEV)
+    ops.in_bwd_stats(dy.to(DEV), ad[..., :C], stats, red)
+    dz = torch.zeros((B, H, W, ld), dtype=tdt, device=DEV)
+    db = torch.zeros((C,), dtype=torch.float32, device=DEV)
+    ops.in_bwd_apply(dy.to(DEV), ad[..., :C], stats, red, dz[..., :C], dbias=db, relu=True)
+    tol = 1e-4 if dt == "f32" else 8e-3
+    assert relerr(dz[..., :C], da_ref) < tol
+    assert relerr(db, da_ref.sum(dim=(0, 1, 2))) < tol
+
+
+def test_spatial_mean_bcast(ops):
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn((3, 10, 12, 256), generator=g)
+    out = torch.zeros((3, 10, 12, 1024), dtype=torch.float32, device=DEV)
+    ops.spatial_mean_bcast(x.to(DEV), out[..., 768:])
+    assert relerr(out[..., 768:], co.global_pool(x.double())) < 1e-5
+    assert float(out[..., :768].abs().max()) == 0.0
+
+
+# ------------------------------------------------------------------------------------ K9-K11
+def _loss_case(ops, logits, labels, ratio, C):
+    n = labels.numel()
+    ld = logits.shape[-1]
+    ce = torch.zeros(n, dtype=torch.float32, device=DEV)
+    probs = torch.zeros((n, C), dtype=torch.float32, device=DEV)
+    bad = torch.zeros(1, dtype=torch.int32, device=DEV)
+    weight = torch.zeros(n, dtype=torch.float32, device=DEV)
+    loss = torch.zeros(4, dtype=torch.float32, device=DEV)
+    dl = torch.zeros((n, ld), dtype=torch.float32, device=DEV)
+    ld_ = logits.to(DEV)
+    lab = labels.to(torch.int32).to(DEV)
+    ops.softmax_ce_fwd(ld_[:, :C], lab, C, ce, probs, bad)
+    ops.hnm_weights(ce, lab, ratio, weight, loss)
+    ops.softmax_ce_bwd(probs, lab, weight, C, dl[:, :C])
+    torch.cuda.synchronize()
+    return ce.cpu(), probs.cpu(), int(bad.item()), weight.cpu(), loss.cpu(), dl.cpu()
+
+
+@pytest.mark.parametrize("C,n,fgfrac,ratio", [(18, 5000, 0.02, 3), (9, 777, 0.3, 3), (5, 4096, 0.001, 3),
+                                              (18, 300, 0.5, 1)])
+def test_softmax_ce_hnm(ops, C, n, fgfrac, ratio):
+    g = torch.Generator().manual_seed(C * 31 + n)
+    ld = (C + 3) // 4 * 4
+    logits = torch.zeros((n, ld))
+    logits[:, :C] = torch.randn((n, C), generator=g) * 2
+    labels = torch.zeros(n, dtype=torch.int64)
+    fg = torch.rand(n, generator=g) < fgfrac
+    labels[fg] = torch.randint(1, C, (int(fg.sum()),), generator=g)
+    # force ties at the selection threshold: duplicate some background rows
+    logits[100:140] = logits[100]
+    labels[100:140] = 0
+    ce, probs, bad, weight, loss, dl = _loss_case(ops, logits, labels, ratio, C)
+    l64 = logits[:, :C].double().requires_grad_(True)
+    ce_ref = co.softmax_ce(l64, labels)
+    loss_ref, w_ref, nfg, nbg = co.hnm_loss(ce_ref, labels, ratio)
+    assert bad == 0
+    assert relerr(ce, ce_ref) < 1e-5
+    assert relerr(probs, torch.softmax(l64, -1)) < 1e-5
+    assert int(loss[1]) == nfg and int(loss[2]) == nbg
+    # the GPU ranks by its own f32 ce; compare selection against the oracle run on those values
+    _, w_sel, _, _ = co.hnm_loss(ce.double(), labels, ratio)
+    assert torch.equal(weight != 0, w_sel != 0)
+    assert relerr(weight, w_sel) < 1e-6
+    assert abs(float(loss[0]) - float(loss_ref)) < 1e-4 * abs(float(loss_ref))
+    (w_sel * ce_ref).sum().backward()
+    assert relerr(dl[:, :C], l64.grad) < 1e-4
+    assert float(dl[:, C:].abs().max()) == 0.0 if ld > C else True
+
+
+def test_hnm_edges(ops):
+    C = 6
+    logits = torch.randn((64, 8))
+    # no foreground -> NaN loss, zero weights
+    ce, probs, bad, weight, loss, dl = _loss_case(ops, logits, torch.zeros(64, dtype=torch.int64), 3, C)
+    assert np.isnan(float(loss[0])) and float(weight.abs().max()) == 0.0
+    # all foreground -> Nbg = 0 -> NaN loss
+    ce, probs, bad, weight, loss, dl = _loss_case(ops, logits, torch.ones(64, dtype=torch.int64), 3, C)
+    assert np.isnan(float(loss[0]))
+    # ratio*Nfg >= Nbg -> every background cell selected
+    labels = torch.zeros(64, dtype=torch.int64)
+    labels[:30] = 2
+    ce, probs, bad, weight, loss, dl = _loss_case(ops, logits, labels, 3, C)
+    assert int(loss[2]) == 34 and int((weight != 0).sum()) == 64
+    # label >= C is reported, not silently used
+    labels[5] = C + 3
+    ce, probs, bad, weight, loss, dl = _loss_case(ops, logits, labels, 3, C)
+    assert bad == 1 and np.isnan(float(ce[5]))
+
+
+# ------------------------------------------------------------------------------------ K12, K14
+def test_l2_norm_adam(ops):
+    g = torch.Generator().manual_seed(11)
+    n = 1_000_003
+    p = torch.randn(n, generator=g)
+    gr = torch.randn(n, generator=g) * 0.05
+    m = torch.randn(n, generator=g) * 0.01
+    v = torch.rand(n, generator=g) * 0.01
+    pd, gd, md, vd = (t.clone().to(DEV) for t in (p, gr, m, v))
+    scratch = torch.zeros(1024, dtype=torch.float32, device=DEV)
+    reg = torch.zeros(1, dtype=torch.float32, device=DEV)
+    wd = 5e-4
+    ops.l2_add(pd, gd, wd, reg, scratch)
+    g_ref = gr.double() + wd * p.double()
+    assert relerr(gd, g_ref) < 1e-6
+    assert abs(float(reg) - float(wd * 0.5 * (p.double() ** 2).sum())) < 1e-4 * float(reg)
+    nsq = torch.zeros(1, dtype=torch.float32, device=DEV)
+    ops.sumsq(gd, nsq, scratch)
+    nsq2 = torch.zeros(1, dtype=torch.float32, device=DEV)
+    ops.sumsq(gd, nsq2, scratch)
+    assert float(nsq) == float(nsq2)            # fixed-order reduction: bit-identical reruns
+    assert abs(float(nsq) - float((g_ref ** 2).sum())) < 1e-4 * float(nsq)
+    for clip in (10.0, 1.0):                    # inactive and active clipping
+        pd2, md2, vd2 = pd.clone(), md.clone(), vd.clone()
+        lr, b1, b2, eps, t = 1e-4, 0.9, 0.999, 1e-8, 3
+        lr_t = lr * np.sqrt(1 - b2 ** t) / (1 - b1 ** t)
+        ops.adam_step(pd2, gd, md2, vd2, lr_t, b1, b2, eps, nsq, clip)
+        state = {"t": t - 1, "m": {"w": m.double()}, "v": {"w": v.double()}}
+        newp = co.adam_step_tf({"w": p.double()}, {"w": g_ref}, state, lr, torch.sqrt((g_ref ** 2).sum()), clip=clip)
+        assert relerr(pd2 - pd, newp["w"] - p.double()) < 1e-4
+        assert relerr(md2, state["m"]["w"]) < 1e-5 and relerr(vd2, state["v"]["w"]) < 1e-5
+
+
+def test_batch_gather_and_convert(ops):
+    g = torch.Generator().manual_seed(12)
+    feat = torch.randn((2, 50, 32), generator=g)
+    idx = torch.randint(-3, 60, (2, 40), generator=g, dtype=torch.int32)
+    out = torch.zeros((2, 40, 160), dtype=torch.float32, device=DEV)
+    ops.batch_gather(feat.to(DEV), idx.to(DEV), out[..., :32])
+    ref = torch.stack([feat[b, idx[b].clamp(0, 49).long()] for b in range(2)])
+    assert torch.equal(out[..., :32].cpu(), ref)
+    dst = torch.zeros((2, 50, 32), dtype=torch.bfloat16, device=DEV)
+    ops.convert(feat.to(DEV), dst)
+    assert torch.equal(dst.cpu(), feat.bfloat16())
