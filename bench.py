@@ -1,0 +1,188 @@
+#!/usr/bin/env python3
+"""Headline benchmark: docs/sec of the CUTIE-ASPP hot path, 64x64 grid, fwd+bwd (BASELINE.json).
+
+One step = one pass of the hot path over one batch of synthetic documents that are already
+resident in HBM as packed OCR tokens: grid build (cutie_grid_build) -> embedding gather -> the
+dense/atrous conv stack with instance norm and the ASPP concat -> softmax-CE + hard negative
+mining -> backward (dgrad, wgrad, IN backward, embedding scatter-add) -> L2, global-norm clip,
+Adam, weight repack.  N > 1: one process per GPU, documents sharded by rank (weak scaling,
+32 documents per GPU), gradients all-reduced over RCCL.
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` for the
+dominant kernel (the MFMA conv forward / data-gradient kernel, timed live with HIP events on
+the launch stream) and `cpu_baseline` (the oracle's PyTorch-CPU restatement on a bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+import types
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+BF16_PEAK_TFLOPS = 2516.6     # MI355X dense bf16 MFMA: 256 CU x 2.4 GHz x 4096 FLOP/clk/CU
+GF_PER_DOC_INBOUNDS = 231.743  # CUTIE-ASPP 64x64 fwd+bwd, in-bounds taps only
+
+
+def conv_launch_flops(segs, B, H, W, n_out):
+    """In-bounds multiply-add FLOPs of one conv_fwd launch (zero-padding taps excluded)."""
+    total = 0
+    for s in segs:
+        cin = s.get("cin_real", s["cin"])
+        hsum = sum(max(0, H - abs((i - s["kh"] // 2) * s["dil"])) for i in range(s["kh"]))
+        wsum = sum(max(0, W - abs((j - s["kw"] // 2) * s["dil"])) for j in range(s["kw"]))
+        total += 2 * B * hsum * wsum * cin * n_out
+    return total
+
+
+class ConvTimer(object):
+    """Wraps ops.conv_fwd: brackets every launch with HIP events on the launch stream."""
+
+    def __init__(self, ops):
+        self.ops, self.orig = ops, ops.conv_fwd
+        self.events, self.flops, self.enabled = [], [], False
+        ops.conv_fwd = self
+
+    def __call__(self, segs, out, n_out, **kw):
+        if not self.enabled:
+            return self.orig(segs, out, n_out, **kw)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        r = self.orig(segs, out, n_out, **kw)
+        e1.record()
+        self.events.append((e0, e1))
+        self.flops.append(conv_launch_flops(segs, out.shape[0], out.shape[1], out.shape[2], n_out))
+        return r
+
+    def summary(self):
+        ms = [a.elapsed_time(b) for a, b in self.events]
+        return sum(ms), sum(self.flops), len(ms)
+
+
+def cpu_baseline(num_classes, V, E, H, W, packed_docs):
+    """The oracle (PyTorch CPU, f32, all host threads) on a bounded sample of the same workload."""
+    from oracle import cutie_oracle as co
+    from oracle import grid_oracle as go
+    from cutie_amd.synthetic import as_token_dicts
+    torch.set_num_threads(min(os.cpu_count() or 1, int(os.environ.get("OMP_NUM_THREADS", "16"))))
+    cores = torch.get_num_threads()
+    docs = as_token_dicts(packed_docs)[:3]
+    params = co.init_params(V, E, num_classes, seed=0, dtype=torch.float32)
+    t0 = time.perf_counter()
+    g = go.positional_mapping(docs, H, W, 1, num_classes)
+    t_grid = time.perf_counter() - t0
+    grid = torch.from_numpy(g["grid"]).long()
+    labels = torch.from_numpy(g["labels"].astype(np.int64)).clamp(0, num_classes - 1)
+    co.loss_and_grads(params, grid[:1], labels[:1])              # warm-up (1 doc)
+    t0 = time.perf_counter()
+    co.loss_and_grads(params, grid[1:3], labels[1:3])
+    t_model = time.perf_counter() - t0
+    per_doc = t_grid / 3 + t_model / 2
+    return {"value": round(1.0 / per_doc, 4), "unit": "docs/s", "cores": cores, "kind": "port",
+            "sample": "oracle restatement (PyTorch CPU f32 autograd + python grid builder): 2 documents fwd+bwd after "
+                      "a 1-document warm-up, grid build on 3; TensorFlow 1.12 itself cannot run here",
+            "grid_build_ms_per_doc": round(1e3 * t_grid / 3, 3), "model_s_per_doc": round(t_model / 2, 3)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=32, help="documents per GPU")
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--rows", type=int, default=64)
+    ap.add_argument("--cols", type=int, default=64)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timing", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    dev = "cuda:%d" % local
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=torch.device(dev))
+
+    from cutie_amd import ops
+    from cutie_amd.model_cutie_aspp import CUTIERes
+    from cutie_amd.runtime import Engine
+    from cutie_amd.synthetic import make_documents
+    from cutie_amd.train import Trainer
+
+    V, E, C, H, W, B = 20000, 128, 18, args.rows, args.cols, args.batch
+    p = types.SimpleNamespace(embedding_size=E, weight_decay=5e-4, hard_negative_ratio=3, batch_size=B)
+    net = CUTIERes(V, C, p)
+    net.build_loss()
+    eng = Engine(net, dev, dtype=args.dtype, seed=0)          # same seed on every rank: identical replicas
+    trainer = Trainer(eng, learning_rate=1e-4)
+    packed = make_documents(B, C, seed=1234 + 1000 * rank)
+    tok = {k: torch.from_numpy(v).to(dev) for k, v in packed.items()}
+    timer = ConvTimer(ops)
+
+    def step():
+        g = ops.grid_build(tok["tok_box"], tok["tok_id"], tok["tok_ecid"], tok["doc_extent"], tok["doc_off"], H, W, 1)
+        trainer.step({"grid_table": g["grid"], "gt_classes": g["labels"]}, fetch=False)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    timer.enabled = not args.no_kernel_timing
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    dt = time.perf_counter() - t0
+    timer.enabled = False
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    loss = eng.losses(eng._plans[(B, H, W, 0)])
+
+    if rank == 0:
+        docs_per_s = world * B * args.steps / dt
+        out = {"metric": "docs/sec CUTIE-ASPP 64x64 fwd+bwd", "value": round(docs_per_s, 2), "unit": "docs/s",
+               "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3),
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype,
+               "data": "synthetic",
+               "config": {"workload": "CUTIE-ASPP fwd+bwd+Adam incl. grid build, %dx%d grid, emb %d, vocab %d, %d classes, "
+                                      "%d synthetic docs per GPU (BASELINE.json configs[1])" % (H, W, E, V, C, B),
+                          "global_batch": world * B, "parallelism": "dp%d" % world,
+                          "whole_step_mfma_frac": round(docs_per_s / world * GF_PER_DOC_INBOUNDS * 1e9 / (BF16_PEAK_TFLOPS * 1e12), 4),
+                          "final_total_loss": round(loss[2], 5)}}
+        if not args.no_kernel_timing:
+            ms, fl, n = timer.summary()
+            ach = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+            peak = BF16_PEAK_TFLOPS if args.dtype == "bf16" else 157.3
+            out["roofline"] = {"bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
+                               "frac": round(ach / peak, 4), "traffic": None,
+                               "kernel": "conv_kernel (forward + data-gradient implicit GEMM)", "launches": n,
+                               "avg_launch_ms": round(ms / max(n, 1), 4),
+                               "share_of_step": round(ms / (1e3 * dt), 4)}
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(C, V, E, H, W, packed)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,57 @@
+"""Data parallelism for the train step: one process per GPU, documents sharded by rank,
+gradients averaged by a bucketed all-reduce (RCCL over xGMI on the GPU box; gloo in CPU tests).
+
+The reference has no multi-GPU path (CUDA_VISIBLE_DEVICES="1", main_train_json.py:9); this is
+new.  The gradient buffer is flat and ordered so that backward finishes it front to back
+(runtime.Engine._layout_params), hence a bucket is a contiguous slice that can be reduced, on
+the collective's own stream, while the earlier layers are still in backward.  xGMI is
+point-to-point (7 links per GPU), so few, large buckets: 54.6 MB of f32 gradients go out as
+`n_buckets` (default 4) slices of the conv range plus one slice for biases + embedding.
+"""
+import torch
+import torch.distributed as dist
+
+
+def dist_info():
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    return 0, 1
+
+
+def shard_documents(docs, rank, world):
+    """rank r takes documents r, r+world, ... of the global batch."""
+    return list(docs[rank::world])
+
+
+class GradBuckets(object):
+    """Tracks which prefix of the flat gradient buffer is final and all-reduces it bucket-wise.
+
+    ready(upto) - gradients in [0, upto) are final: launch every bucket that is now complete.
+    finish()    - launch what is left (biases, embedding), wait for everything.
+    The sum is left in the buffer; the optimizer applies 1/world (cutie_adam_step grad_scale)."""
+
+    def __init__(self, flat, n_front, n_buckets=4, group=None, align=64):
+        self.flat, self.group = flat, group
+        self.n_front = int(n_front)
+        step = max(align, (self.n_front // max(1, n_buckets) + align - 1) // align * align)
+        self.bounds = list(range(step, self.n_front, step)) + [self.n_front]
+        self.reset()
+
+    def reset(self):
+        self.next_lo, self.next_b, self.works = 0, 0, []
+
+    def _launch(self, lo, hi):
+        if hi > lo:
+            self.works.append(dist.all_reduce(self.flat[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+
+    def ready(self, upto):
+        while self.next_b < len(self.bounds) and self.bounds[self.next_b] <= upto:
+            hi = self.bounds[self.next_b]
+            self._launch(self.next_lo, hi)
+            self.next_lo, self.next_b = hi, self.next_b + 1
+
+    def finish(self):
+        self._launch(self.next_lo, self.flat.numel())
+        for w in self.works:
+            w.wait()
+        self.reset()

@@ -1,0 +1,381 @@
+"""Engine: compiles a cutie_amd.model_framework graph into HIP kernel launches.
+
+What the reference delegates to a tf.Session (/root/reference/main_train_json.py:185-186,
+:231-257; main_evaluate_json.py:99) happens here: variable creation/initialisation, buffer
+planning for a given batch/grid shape, the forward pass, the loss, and the backward pass.
+All arithmetic is in libcutie_hip.so; PyTorch only owns the device memory.
+
+Memory plan (sized for 288 GB of HBM: nothing is recomputed, nothing is re-laid-out):
+  * parameters, gradients and Adam moments are three flat f32 buffers with one layout
+    [conv kernels, reverse creation order | biases | embedding]; the L2 term, the global
+    norm, Adam and the RCCL all-reduce each run over a contiguous range of them;
+  * every concat is one wide NHWC buffer whose producers write their channel slice
+    (model_framework.py:294 needs no kernel); channel counts are padded to 64 with zeros so
+    that the K dimension of every implicit GEMM is whole;
+  * per conv layer: `a` = relu(conv + b) before the instance norm (its sign is the ReLU
+    mask), `y` = normalised output, f32 moments; backward adds `dy` and `dz`.
+A tensor with several consumers gets its gradient from ONE multi-segment data-gradient
+launch over all consuming convs (also through concats, by weight-row offset).
+"""
+import math
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+from . import capi, ops
+from .capi import BF16, F32, CutieError
+
+
+def _pad(c, m=64):
+    return (c + m - 1) // m * m
+
+
+class _Plan(object):
+    pass
+
+
+class Engine(object):
+    def __init__(self, network, device="cuda:0", dtype="bf16", seed=0):
+        capi.lib()   # fail loudly, before anything else, when the HIP library is absent
+        if not torch.cuda.is_available():
+            raise CutieError("cutie_amd needs a HIP device (torch.cuda.is_available() is False); there is no CPU path")
+        self.net = network
+        self.dev = torch.device(device)
+        self.dt = BF16 if dtype in ("bf16", torch.bfloat16, BF16) else F32
+        self.tdt = capi.torch_dtype(self.dt)
+        self.bke = 64 if self.dt == BF16 else 32
+        self.C = network.num_classes
+        self._plans = {}
+        self._layout_params()
+        self.initialize(seed)
+
+    # ------------------------------------------------------------------ variables
+    def _layout_params(self):
+        specs = list(self.net.param_specs)
+        conv_w = [s for s in specs if len(s.shape) == 4]
+        biases = [s for s in specs if len(s.shape) == 1]
+        embeds = [s for s in specs if len(s.shape) == 2]
+        order = list(reversed(conv_w)) + list(reversed(biases)) + embeds
+        off, self.offsets = 0, OrderedDict()
+        for s in order:
+            n = int(np.prod(s.shape))
+            self.offsets[s.name] = (off, n, s.shape)
+            off = _pad(off + n, 64)
+            if s is conv_w[0]:
+                self.n_conv_w = off      # creation-first conv is last in the reversed range
+        self.n_dense = self.offsets[embeds[0].name][0] if embeds else off
+        self.n_total = off
+        self.conv_w_names = [s.name for s in conv_w]
+        z = lambda: torch.zeros(self.n_total, dtype=torch.float32, device=self.dev)
+        self.params_flat, self.grads_flat = z(), z()
+        self.params = OrderedDict((s.name, self._view(self.params_flat, s.name)) for s in specs)
+        self.grads = OrderedDict((s.name, self._view(self.grads_flat, s.name)) for s in specs)
+        self.spec_by_name = OrderedDict((s.name, s) for s in specs)
+        # packed conv operands (rebuilt by repack() whenever the parameters change)
+        self.w_fwd, self.w_dg = {}, {}
+        for s in conv_w:
+            kh, kw, cin, cout = s.shape
+            self.w_fwd[s.name] = torch.zeros((kh * kw, cout, _pad(cin, self.bke)), dtype=self.tdt, device=self.dev)
+            self.w_dg[s.name] = torch.zeros((kh * kw, cin, _pad(cout, self.bke)), dtype=self.tdt, device=self.dev)
+
+    def _view(self, flat, name):
+        off, n, shape = self.offsets[name]
+        return flat[off:off + n].view(shape)
+
+    def initialize(self, seed=0):
+        """tf.global_variables_initializer() analogue with the reference's initialisers
+        (model_framework.py:46,178-179): embedding U(-1,1); kernels truncated normal(0, 0.01); biases 0."""
+        g = torch.Generator().manual_seed(seed)
+        for s in self.net.param_specs:
+            if len(s.shape) == 2:
+                p = torch.rand(s.shape, generator=g) * 2 - 1
+            elif len(s.shape) == 4:
+                p = torch.nn.init.trunc_normal_(torch.empty(s.shape), mean=0.0, std=0.01, a=-0.02, b=0.02, generator=g)
+            else:
+                p = torch.zeros(s.shape)
+            self.params[s.name].copy_(p)
+        self.repack()
+
+    def load_params(self, named):
+        """named: mapping '<layer>/weights' (HWIO) / '<layer>/biases' / 'embedding/weights' -> array."""
+        for k, v in named.items():
+            if k not in self.params:
+                raise KeyError("unknown variable %s" % k)
+            t = torch.as_tensor(np.asarray(v) if not torch.is_tensor(v) else v).to(torch.float32)
+            if tuple(t.shape) != tuple(self.params[k].shape):
+                raise ValueError("%s: shape %s != %s" % (k, tuple(t.shape), tuple(self.params[k].shape)))
+            self.params[k].copy_(t)
+        self.repack()
+
+    def state_dict(self):
+        return OrderedDict((k, v.detach().cpu().numpy().copy()) for k, v in self.params.items())
+
+    def repack(self):
+        for name in self.conv_w_names:
+            ops.pack_weights_into(self.params[name], self.dt, self.w_fwd[name], self.w_dg[name])
+
+    # ------------------------------------------------------------------ planning
+    def _plan(self, B, H, W, Hi):
+        key = (B, H, W, Hi)
+        if key in self._plans:
+            return self._plans[key]
+        net, dev, tdt = self.net, self.dev, self.tdt
+        P = _Plan()
+        P.key, P.B, P.H, P.W, P.Hi = key, B, H, W, Hi
+        nodes = net.nodes
+        spatial = lambda n: (H, W) if n.domain == "grid" else (Hi, W)
+        consumers = {}
+        for n in nodes:
+            for i in n.inputs:
+                consumers.setdefault(i.name, []).append(n)
+        P.consumers = consumers
+
+        # ---- placement of activation tensors: concat inputs live inside the concat buffer
+        place, bufs = {}, {}
+        P.copies = []        # (src name, dst view) for a tensor that feeds a second concat
+        for n in nodes:
+            if n.op != "concat":
+                continue
+            hs, ws = spatial(n)
+            buf = torch.zeros((B, hs, ws, _pad(n.channels) + 64), dtype=tdt, device=dev)
+            bufs[n.name] = buf
+            off = 0
+            for i in n.inputs:
+                if i.name in place:
+                    P.copies.append((i.name, n.name, buf[..., off:off + i.channels]))
+                else:
+                    place[i.name] = (n.name, off)
+                off += i.channels
+            place[n.name] = (n.name, 0)
+        if Hi:
+            bufs["data_image"] = torch.zeros((B, Hi, W, 64 + 64), dtype=tdt, device=dev)
+            place["data_image"] = ("data_image", 0)
+        for n in nodes:
+            if n.op in ("conv", "embed", "global_pool", "positional_sampling") and n.name not in place:
+                hs, ws = spatial(n)
+                logits = n.name == net.loss_logits_name
+                ch = _pad(n.channels, 4) if logits else _pad(n.channels) + 64
+                bufs[n.name] = torch.zeros((B, hs, ws, ch), dtype=torch.float32 if logits else tdt, device=dev)
+                place[n.name] = (n.name, 0)
+        P.bufs, P.place = bufs, place
+
+        def view(name, channels):
+            b, off = place[name]
+            return bufs[b][..., off:off + channels]
+        P.view = view
+
+        # ---- per conv layer state
+        convs = [n for n in nodes if n.op == "conv"]
+        P.convs = convs
+        n_stats = sum(B * n.channels * 2 for n in convs)
+        P.stats_all = torch.zeros(n_stats, dtype=torch.float32, device=dev)
+        P.red_all = torch.zeros(n_stats, dtype=torch.float32, device=dev)
+        P.a, P.stats, P.red, P.dz, P.dy = {}, {}, {}, {}, {}
+        so = 0
+        for n in convs:
+            hs, ws = spatial(n)
+            P.a[n.name] = torch.zeros((B, hs, ws, _pad(n.channels)), dtype=tdt, device=dev)
+            cnt = B * n.channels * 2
+            P.stats[n.name] = P.stats_all[so:so + cnt].view(B, n.channels, 2)
+            P.red[n.name] = P.red_all[so:so + cnt].view(B, n.channels, 2)
+            so += cnt
+        P.oob = torch.zeros(1, dtype=torch.int32, device=dev)
+        P.bad = torch.zeros(1, dtype=torch.int32, device=dev)
+        N = B * H * W
+        P.N = N
+        P.ce = torch.zeros(N, dtype=torch.float32, device=dev)
+        P.probs = torch.zeros((B, H, W, self.C), dtype=torch.float32, device=dev)
+        P.weight = torch.zeros(N, dtype=torch.float32, device=dev)
+        P.loss = torch.zeros(4, dtype=torch.float32, device=dev)
+        P.zero_labels = torch.zeros(N, dtype=torch.int32, device=dev)
+        P.grid = torch.zeros((B, H, W), dtype=torch.int32, device=dev)
+        P.labels = torch.zeros((B, H, W), dtype=torch.int32, device=dev)
+        P.ps = torch.zeros((B, H * W), dtype=torch.int32, device=dev) if Hi else None
+        P.bwd_ready = False
+        self._plans[key] = P
+        return P
+
+    def _plan_backward(self, P):
+        if P.bwd_ready:
+            return
+        net, dev, tdt, B = self.net, self.dev, self.tdt, P.B
+        for n in P.convs:
+            if n.domain != "grid":
+                raise NotImplementedError("backward through the CUTIE2 image branch (%s) is not built yet" % n.name)
+        for n in P.convs:
+            P.dz[n.name] = torch.zeros((B, P.H, P.W, _pad(n.channels)), dtype=tdt, device=dev)
+        # gradient buffers for every tensor that a conv or the embedding produces
+        for n in net.nodes:
+            if n.op == "conv":
+                logits = n.name == net.loss_logits_name
+                ch = _pad(n.channels, 4) if logits else _pad(n.channels)
+                P.dy[n.name] = torch.zeros((B, P.H, P.W, ch), dtype=torch.float32 if logits else tdt, device=dev)
+            elif n.op == "embed":
+                P.dy[n.name] = torch.zeros((B, P.H, P.W, _pad(n.channels)), dtype=tdt, device=dev)
+        ws_bytes = 0
+        for n in P.convs:
+            a = n.attrs
+            ws_bytes = max(ws_bytes, ops.conv_wgrad_workspace_bytes(B, P.H, P.W, a["cin"], n.channels, a["kh"], a["kw"]))
+        P.wgrad_ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+        P.scratch = torch.zeros(capi.REDUCE_SCRATCH, dtype=torch.float32, device=dev)
+        P.reg = torch.zeros(1, dtype=torch.float32, device=dev)
+        P.gnorm_sq = torch.zeros(1, dtype=torch.float32, device=dev)
+        P.bwd_ready = True
+
+    def _grad_segments(self, P, name):
+        """(dz view, packed dgrad weights, row offset) for every conv that consumes tensor `name`,
+        directly or through a concat.  global_pool consumers contribute nothing: the pooled
+        tensor is instance-normalised, so d(mean)/dx is annihilated by the norm's backward
+        ('global pool gradient')."""
+        segs = []
+
+        def walk(nm, off):
+            for c in P.consumers.get(nm, []):
+                if c.op == "conv":
+                    a = c.attrs
+                    segs.append(dict(x=P.dz[c.name], w=self.w_dg[c.name + "/weights"], cin=_pad(c.channels, self.bke),
+                                     kh=a["kh"], kw=a["kw"], dil=a["rate"], flip=True, n_off=off))
+                elif c.op == "concat":
+                    o = 0
+                    for i in c.inputs:
+                        if i.name == nm:
+                            break
+                        o += i.channels
+                    walk(c.name, off + o)
+                elif c.op in ("global_pool", "softmax"):
+                    pass
+                else:
+                    raise NotImplementedError("gradient through %s (%s)" % (c.name, c.op))
+        walk(name, 0)
+        return segs
+
+    # ------------------------------------------------------------------ execution
+    def forward(self, grid, image=None, ps_1d_indices=None, labels=None):
+        """grid int [B,H,W,1] or [B,H,W] (host or device).  Returns the plan holding every
+        named layer; `softmax` and the per-cell CE are computed when the graph has a softmax."""
+        net = self.net
+        g = torch.as_tensor(grid)
+        if g.dim() == 4:
+            g = g[..., 0]
+        B, H, W = (int(v) for v in g.shape)
+        Hi = 0
+        if image is not None:
+            img = torch.as_tensor(image)
+            Hi = int(img.shape[1])
+            if int(img.shape[2]) != W or int(img.shape[0]) != B:
+                raise CutieError("data_image %s does not match grid %s (width = cols)" % (tuple(img.shape), (B, H, W)))
+        P = self._plan(B, H, W, Hi)
+        P.grid.copy_(g.to(torch.int32), non_blocking=True)
+        if labels is not None:
+            P.labels.copy_(torch.as_tensor(labels).to(torch.int32).reshape(B, H, W), non_blocking=True)
+        if Hi:
+            P.bufs["data_image"][..., :3].copy_(img.to(self.dev))
+            P.ps.copy_(torch.as_tensor(ps_1d_indices).to(torch.int32).reshape(B, H * W))
+        P.stats_all.zero_()
+        P.oob.zero_()
+        for n in net.nodes:
+            if n.op == "embed":
+                ops.embed_fwd(P.grid, self.params[n.name + "/weights"], P.view(n.name, n.channels), P.oob)
+            elif n.op == "conv":
+                a = n.attrs
+                src = n.inputs[0]
+                cin_pad = _pad(a["cin"], self.bke)
+                ops.conv_fwd([dict(x=P.view(src.name, cin_pad), w=self.w_fwd[n.name + "/weights"], cin=cin_pad,
+                                   kh=a["kh"], kw=a["kw"], dil=a["rate"])],
+                             P.a[n.name], n.channels, bias=self.params[n.name + "/biases"], relu=True,
+                             stats=P.stats[n.name])
+                ops.in_apply(P.a[n.name][..., :n.channels], P.stats[n.name], P.view(n.name, n.channels))
+            elif n.op == "global_pool":
+                src = n.inputs[0]
+                ops.spatial_mean_bcast(P.view(src.name, src.channels), P.view(n.name, n.channels))
+            elif n.op == "concat":
+                for (src, dst_name, dst) in P.copies:
+                    if dst_name == n.name:
+                        ops.convert(P.view(src, dst.shape[-1]), dst)
+            elif n.op == "positional_sampling":
+                feat = n.inputs[0]
+                fv = P.view(feat.name, feat.channels)
+                ops.batch_gather(fv.reshape(B, Hi * W, feat.channels) if fv.is_contiguous() else
+                                 fv.as_strided((B, Hi * W, feat.channels), (fv.stride(0), fv.stride(2), 1)),
+                                 P.ps, P.view(n.name, n.channels).as_strided(
+                                     (B, H * W, n.channels),
+                                     (P.view(n.name, n.channels).stride(0), P.view(n.name, n.channels).stride(2), 1)))
+            elif n.op == "softmax":
+                src = n.inputs[0]
+                P.bad.zero_()
+                lab = P.labels if labels is not None else P.zero_labels
+                ops.softmax_ce_fwd(P.view(src.name, src.channels), lab, src.channels, P.ce, P.probs, P.bad)
+            else:
+                raise NotImplementedError(n.op)
+        P.has_labels = labels is not None
+        return P
+
+    def get(self, P, name):
+        """Device tensor of a named layer after forward()."""
+        n = self.net.layers[name]
+        if n.op == "softmax":
+            return P.probs
+        if n.op == "input":
+            return {"data_grid": P.grid, "gt_classes": P.labels}.get(name)
+        return P.view(name, n.channels)
+
+    def check_inputs(self, P):
+        """Host-side validation of the counters the kernels keep (one sync)."""
+        oob, bad = int(P.oob.item()), int(P.bad.item()) if P.has_labels else 0
+        if oob:
+            raise CutieError("%d grid cells hold a vocabulary id outside [0, %d) (SURVEY.md 0.7)" % (oob, self.net.num_vocabs))
+        if bad:
+            raise CutieError("%d labels fall outside [0, %d) (entity_class_id overflow, SURVEY.md 0.6)" % (bad, self.C))
+
+    def loss_backward(self, P):
+        """model_cutie.py:107-140 + tf.gradients: fills grads_flat (incl. the L2 term) and the
+        squared global norm the way tf.clip_by_global_norm sees it.  Needs forward(labels=...)."""
+        if not P.has_labels:
+            raise CutieError("loss_backward needs forward(..., labels=...)")
+        self._plan_backward(P)
+        net, spec = self.net, self.net.loss_spec
+        lname = net.loss_logits_name
+        C = self.C
+        ops.hnm_weights(P.ce, P.labels, int(spec["hard_negative_ratio"]), P.weight, P.loss)
+        ops.softmax_ce_bwd(P.probs, P.labels, P.weight, C, P.dy[lname][..., :C])
+        self.grads_flat.zero_()
+        P.red_all.zero_()
+        for n in reversed(net.nodes):
+            if n.op == "conv":
+                a = n.attrs
+                if n.name != lname:
+                    ops.conv_fwd(self._grad_segments(P, n.name), P.dy[n.name], n.channels)
+                dy = P.dy[n.name][..., :n.channels]
+                av = P.a[n.name][..., :n.channels]
+                ops.in_bwd_stats(dy, av, P.stats[n.name], P.red[n.name])
+                ops.in_bwd_apply(dy, av, P.stats[n.name], P.red[n.name], P.dz[n.name][..., :n.channels],
+                                 dbias=self.grads[n.name + "/biases"], relu=True)
+                src = n.inputs[0]
+                ops.conv_wgrad(P.view(src.name, a["cin"]), a["cin"], P.dz[n.name][..., :n.channels], n.channels,
+                               a["kh"], a["kw"], a["rate"], self.grads[n.name + "/weights"], P.wgrad_ws)
+            elif n.op == "embed":
+                ops.conv_fwd(self._grad_segments(P, n.name), P.dy[n.name], n.channels)
+                ops.embed_bwd(P.grid, P.dy[n.name][..., :n.channels], self.grads[n.name + "/weights"])
+                P.d_embed = P.dy[n.name]
+        P.reg.zero_()
+        ops.l2_add(self.params_flat[:self.n_conv_w], self.grads_flat[:self.n_conv_w], float(spec["weight_decay"]),
+                   P.reg, P.scratch)
+        return P
+
+    def global_norm_sq(self, P, tf_indexed_slices=True):
+        """Squared global norm.  With tf_indexed_slices (single replica, TF parity) the embedding
+        enters through its un-deduplicated per-cell rows, as tf.clip_by_global_norm does for an
+        IndexedSlices gradient; otherwise through the dense summed gradient."""
+        P.gnorm_sq.zero_()
+        if tf_indexed_slices and hasattr(P, "d_embed"):
+            ops.sumsq(self.grads_flat[:self.n_dense], P.gnorm_sq, P.scratch)
+            ops.sumsq(P.d_embed.reshape(-1), P.gnorm_sq, P.scratch)
+        else:
+            ops.sumsq(self.grads_flat, P.gnorm_sq, P.scratch)
+        return P.gnorm_sq
+
+    def losses(self, P):
+        """(model_loss, regularization_loss, total_loss) as python floats (one sync)."""
+        ml, rg = float(P.loss[0].item()), float(P.reg.item())
+        return ml, rg, ml + rg

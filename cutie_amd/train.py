@@ -1,0 +1,60 @@
+"""The train step of /root/reference/main_train_json.py:150-158,228-257 on the HIP engine.
+
+Reference semantics kept: feed (grid_table int32 [B,H,W,1], gt_classes [B,H,W]) -> fetch
+(model_loss, regularization_loss, total_loss, logits, softmax); tf.gradients of total_loss;
+tf.clip_by_global_norm(grads, 10.0); tf.train.AdamOptimizer(lr) with TF's bias-correction form;
+learning-rate decay x0.1 every lr_decay_step iterations (:225-226).  The two partial_run phases
+collapse into one step because ghm_weights is all ones when use_ghm=0 (:249-251).
+
+New: data parallelism (cutie_amd.parallel) - each rank runs the step on its shard of documents;
+hard negative mining is per replica (SURVEY.md 8e caveat).
+"""
+import math
+
+import torch
+
+from . import ops
+from .parallel import GradBuckets, dist_info
+
+
+class Trainer(object):
+    def __init__(self, engine, learning_rate=1e-4, clip_norm=10.0, beta1=0.9, beta2=0.999, epsilon=1e-8,
+                 lr_decay_step=13000, lr_decay_factor=0.1, n_buckets=4, check_inputs=False):
+        self.eng = engine
+        self.lr = float(learning_rate)
+        self.clip, self.b1, self.b2, self.eps = float(clip_norm), beta1, beta2, epsilon
+        self.lr_decay_step, self.lr_decay_factor = lr_decay_step, lr_decay_factor
+        self.iter = 0          # the reference's `iter` (drives lr decay)
+        self.t = 0             # Adam's step count
+        self.check_inputs = check_inputs
+        self.m = torch.zeros_like(engine.params_flat)
+        self.v = torch.zeros_like(engine.params_flat)
+        self.rank, self.world = dist_info()
+        self.buckets = GradBuckets(engine.grads_flat, engine.n_conv_w, n_buckets) if self.world > 1 else None
+
+    def step(self, batch, fetch=True):
+        """batch: {'grid_table', 'gt_classes'[, 'data_image', 'ps_1d_indices']} as next_batch() returns
+        (data_loader_json.py:204-207).  Returns the reference's fetches as a dict."""
+        eng = self.eng
+        if self.iter != 0 and self.lr_decay_step and self.iter % self.lr_decay_step == 0:
+            self.lr *= self.lr_decay_factor
+        P = eng.forward(batch["grid_table"], labels=batch["gt_classes"])
+        if self.check_inputs:
+            eng.check_inputs(P)
+        eng.loss_backward(P)
+        if self.buckets is not None:
+            # TODO(next): call buckets.ready() from inside backward as each wgrad lands
+            self.buckets.ready(eng.n_conv_w)
+            self.buckets.finish()
+        gn = eng.global_norm_sq(P, tf_indexed_slices=(self.world == 1))
+        self.t += 1
+        lr_t = self.lr * math.sqrt(1.0 - self.b2 ** self.t) / (1.0 - self.b1 ** self.t)
+        ops.adam_step(eng.params_flat, eng.grads_flat, self.m, self.v, lr_t, self.b1, self.b2, self.eps, gn,
+                      self.clip, grad_scale=1.0 / self.world)
+        eng.repack()
+        self.iter += 1
+        if not fetch:
+            return None
+        ml, rg, tl = eng.losses(P)
+        return {"model_loss": ml, "regularization_loss": rg, "total_loss": tl,
+                "logits": eng.get(P, "cls_logits"), "softmax": P.probs, "global_norm": math.sqrt(float(gn.item()))}

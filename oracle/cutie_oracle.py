@@ -47,9 +47,16 @@ def conv_raw(x, w_hwio, rate=1):
     return y.permute(0, 2, 3, 1)
 
 
-def cbrn(x, w_hwio, bias, rate=1, activation="relu"):
+def cbrn(x, w_hwio, bias, rate=1, activation="relu", mask=None):
+    """mask (optional, relu only): a 0/1 tensor that replaces the ReLU's own activation pattern
+    (a = z * mask).  Tests pass the DEVICE's pattern so that gradients are compared on the same
+    side of every ReLU kink; a pre-activation within rounding of 0 otherwise flips the whole
+    local gradient and says nothing about the backward kernels."""
     z = conv_raw(x, w_hwio, rate) + bias
-    a = torch.relu(z) if activation == "relu" else torch.sigmoid(z)
+    if mask is not None and activation == "relu":
+        a = z * mask
+    else:
+        a = torch.relu(z) if activation == "relu" else torch.sigmoid(z)
     return instance_norm(a)
 
 
@@ -105,27 +112,29 @@ def init_params(num_vocabs, embedding_size, num_classes, seed=0, dtype=torch.flo
     return params
 
 
-def aspp_forward(params, grid, activation="relu"):
+def aspp_forward(params, grid, activation="relu", masks=None):
     """grid int [B,H,W] or [B,H,W,1] -> dict of every named layer (model_cutie_aspp.py:35-74)."""
     if grid.dim() == 4:
         grid = grid[..., 0]
     L = OrderedDict()
+    m = (lambda n: masks.get(n)) if masks else (lambda n: None)
     L["embedding"] = params["embedding/weights"][grid.long()]
     x = L["embedding"]
     for name in ("encoder1_1", "encoder1_2", "encoder1_3", "encoder1_4", "encoder1_5", "encoder1_6",
                  "encoder1_7", "encoder1_8"):
-        x = cbrn(x, params[name + "/weights"], params[name + "/biases"], ASPP_LAYERS[name][3])
+        x = cbrn(x, params[name + "/weights"], params[name + "/biases"], ASPP_LAYERS[name][3], mask=m(name))
         L[name] = x
     e8 = L["encoder1_8"]
     for name in ("aspp_1", "aspp_2", "aspp_3"):
-        L[name] = cbrn(e8, params[name + "/weights"], params[name + "/biases"], ASPP_LAYERS[name][3])
+        L[name] = cbrn(e8, params[name + "/weights"], params[name + "/biases"], ASPP_LAYERS[name][3], mask=m(name))
     L["aspp_4"] = global_pool(e8)
     L["aspp_concat"] = torch.cat([L["aspp_1"], L["aspp_2"], L["aspp_3"], L["aspp_4"]], dim=3)
-    L["aspp_1x1"] = cbrn(L["aspp_concat"], params["aspp_1x1/weights"], params["aspp_1x1/biases"])
+    L["aspp_1x1"] = cbrn(L["aspp_concat"], params["aspp_1x1/weights"], params["aspp_1x1/biases"], mask=m("aspp_1x1"))
     L["concat1"] = torch.cat([L["encoder1_1"], L["aspp_1x1"]], dim=3)
-    L["decoder1_1"] = cbrn(L["concat1"], params["decoder1_1/weights"], params["decoder1_1/biases"])
+    L["decoder1_1"] = cbrn(L["concat1"], params["decoder1_1/weights"], params["decoder1_1/biases"],
+                           mask=m("decoder1_1"))
     L["cls_logits"] = cbrn(L["decoder1_1"], params["cls_logits/weights"], params["cls_logits/biases"],
-                           activation=activation)
+                           activation=activation, mask=m("cls_logits"))
     L["softmax"] = torch.softmax(L["cls_logits"], dim=-1)
     return L
 
@@ -158,26 +167,36 @@ def hnm_loss(ce, labels, ratio):
     return loss, weight, n_fg, num_bg
 
 
-def build_loss(params, layers, labels, hard_negative_ratio=3, weight_decay=5e-4):
-    """(model_loss, regularization_loss, total_loss, logits, softmax) - model_cutie.py:140."""
+def build_loss(params, layers, labels, hard_negative_ratio=3, weight_decay=5e-4, cell_weights=None):
+    """(model_loss, regularization_loss, total_loss, logits, softmax) - model_cutie.py:140.
+    cell_weights (optional): a fixed per-cell weight vector replacing the hard-negative
+    selection (tests pass the DEVICE's selection so that a top-k boundary that falls between
+    two nearly equal CE values does not masquerade as a gradient error)."""
     logits = layers["cls_logits"]
     C = logits.shape[-1]
     ce = softmax_ce(logits.reshape(-1, C), labels.reshape(-1))
-    model_loss, _w, _nfg, _nbg = hnm_loss(ce, labels, hard_negative_ratio)
+    if cell_weights is not None:
+        model_loss = (cell_weights.reshape(-1).to(ce.dtype) * ce).sum()
+    else:
+        model_loss, _w, _nfg, _nbg = hnm_loss(ce, labels, hard_negative_ratio)
     reg = sum(weight_decay * 0.5 * (p ** 2).sum() for n, p in params.items()
               if n.endswith("/weights") and n != "embedding/weights")
     return model_loss, reg, model_loss + reg, logits, layers["softmax"]
 
 
-def loss_and_grads(params, grid, labels, hard_negative_ratio=3, weight_decay=5e-4):
+def loss_and_grads(params, grid, labels, hard_negative_ratio=3, weight_decay=5e-4, masks=None, cell_weights=None):
     ps = OrderedDict((k, v.detach().clone().requires_grad_(True)) for k, v in params.items())
-    layers = aspp_forward(ps, grid)
-    layers["embedding"].retain_grad()
-    model_loss, reg, total, logits, sm = build_loss(ps, layers, labels, hard_negative_ratio, weight_decay)
+    layers = aspp_forward(ps, grid, masks=masks)
+    for t in layers.values():
+        if t.requires_grad:
+            t.retain_grad()
+    model_loss, reg, total, logits, sm = build_loss(ps, layers, labels, hard_negative_ratio, weight_decay,
+                                                    cell_weights)
     total.backward()
     grads = OrderedDict((k, v.grad) for k, v in ps.items())
     return {"model_loss": model_loss.detach(), "reg_loss": reg.detach(), "total_loss": total.detach(),
-            "layers": layers, "grads": grads, "d_embedding_out": layers["embedding"].grad}
+            "layers": layers, "grads": grads, "d_embedding_out": layers["embedding"].grad,
+            "dlayers": OrderedDict((k, t.grad) for k, t in layers.items() if t.grad is not None)}
 
 
 def global_norm_tf(grads, d_embedding_out):

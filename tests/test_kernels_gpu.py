@@ -362,7 +362,7 @@ def test_softmax_ce_hnm(ops, C, n, fgfrac, ratio):
     _, w_sel, _, _ = co.hnm_loss(ce.double(), labels, ratio)
     assert torch.equal(weight != 0, w_sel != 0)
     assert relerr(weight, w_sel) < 1e-6
-    assert abs(float(loss[0]) - float(loss_ref)) < 1e-4 * abs(float(loss_ref))
+    assert abs(float(loss[0]) - float(loss_ref.detach())) < 1e-4 * abs(float(loss_ref.detach()))
     (w_sel * ce_ref).sum().backward()
     assert relerr(dl[:, :C], l64.grad) < 1e-4
     assert float(dl[:, C:].abs().max()) == 0.0 if ld > C else True
@@ -417,7 +417,9 @@ def test_l2_norm_adam(ops):
         ops.adam_step(pd2, gd, md2, vd2, lr_t, b1, b2, eps, nsq, clip)
         state = {"t": t - 1, "m": {"w": m.double()}, "v": {"w": v.double()}}
         newp = co.adam_step_tf({"w": p.double()}, {"w": g_ref}, state, lr, torch.sqrt((g_ref ** 2).sum()), clip=clip)
-        assert relerr(pd2 - pd, newp["w"] - p.double()) < 1e-4
+        # the update (~1e-4) is read back as a difference of f32 parameters (~1): ulp/update ~ 6e-4
+        assert relerr(pd2.double() - pd.double(), newp["w"] - p.double()) < 2e-3
+        assert relerr(pd2, newp["w"]) < 1e-6
         assert relerr(md2, state["m"]["w"]) < 1e-5 and relerr(vd2, state["v"]["w"]) < 1e-5
 
 
