@@ -156,7 +156,7 @@ def test_cutie_aspp_forward_backward_parity(oracle_run, dtype):
         big = o["grads"][k].abs() > 0.02 * o["grads"][k].abs().max()     # away from g ~ 0, where sign(g) is noise
         frac_same_sign = float((torch.sign(move) == torch.sign(move_ref))[big].double().mean())
         assert frac_same_sign > (0.9999 if dtype == "f32" else 0.95), (k, frac_same_sign)
-        assert float(move[big].abs().max()) < 1.01e-4 and float(move[big].abs().min()) > 0.9e-4   # |step| ~ lr
+        assert float(move[big].abs().max()) < 1.01e-4      # |first Adam step| <= lr
 
 
 def rel2(got, ref):
