@@ -29,6 +29,7 @@
 //   K is split over row groups into f32 slabs, summed by wgrad_reduce_kernel in a fixed order
 //   (deterministic, no float atomics).
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 using namespace cutie;
@@ -55,6 +56,7 @@ struct ConvParams {
     float* stats;
     int TH, TWB, tiles_h, tiles_w, n_tiles_n;
     int a_bytes;  // LDS bytes reserved for the A patch
+    int dbg;
 };
 
 template <int DT> struct Traits;
@@ -76,20 +78,47 @@ __device__ __forceinline__ void mma_frag(const uint4& a, const uint4& b, float4_
     }
 }
 
+constexpr int CONV_NT = 256;     // lanes per workgroup: 4 waves as 2 (pixel halves) x 2 (channel halves)
+constexpr int CONV_MB = 8;       // 16-pixel blocks per wave: a wave owns 128 pixels x 64 channels
+constexpr int CONV_NA = 6;       // 16-byte chunks of the A patch each lane stages per batch
+
+// columns of the staged patch: image columns [w0 - padl, w0 + TW + padr); a live 16-pixel block
+// never reads left of column -15 or right of W + 14, so the halo is clipped to that
+__device__ __forceinline__ void conv_geom(int kw, int dil, int w0, int TW, int W, int& padl, int& pw) {
+    const int pad = (kw / 2) * dil;
+    padl = min(pad, w0 + 15);
+    const int padr = max(0, min(pad, W + 15 - (w0 + TW)));
+    pw = padl + TW + padr;
+}
+
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
+constexpr unsigned BUF_OOB = 0x80000000u;   // beyond any num_records: the buffer load returns zeros
+
+__device__ __forceinline__ uint4 buf_load16(__amdgpu_buffer_rsrc_t rsrc, unsigned voff) {
+    const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)voff, 0, 0);
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
+
+// Workgroup tile = 256 pixels (TH rows x TWB*16 columns of one sample) x 128 output channels.
+// Per (segment, tap row, 128-byte channel chunk) the input row patch is staged once and reused by
+// the kw column taps; the weight tile of tap j+1 is fetched into registers while tap j computes
+// and lands in the other half of a double-buffered LDS tile (one barrier per tap).
 template <int DT, int ODT>
-__global__ __launch_bounds__(256) void conv_kernel(ConvParams p) {
+__global__ __launch_bounds__(CONV_NT, 2) void conv_kernel(ConvParams p) {
     constexpr int ES = Traits<DT>::ES;
     constexpr int BKE = Traits<DT>::BKE;
     typedef typename elem<ODT>::type TO;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* As = smem;
-    char* Bs = smem + p.a_bytes;
+    char* As = smem;                    // [TH][PW][8 chunks] x 16 B, chunk index swizzled
+    char* Bs = smem + p.a_bytes;        // 2 x [128 rows][8 chunks] x 16 B
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
     const int li = lane & 15, lg = lane >> 4;
+    const int H = p.H, W = p.W, TH = p.TH, TWB = p.TWB, n_out = p.n_out, dbg = p.dbg;
+    if (dbg & 128) return;
 
     // workgroup -> (sample, tile row, tile col, channel tile); channel tile fastest
     int bid = blockIdx.x;
@@ -97,114 +126,146 @@ __global__ __launch_bounds__(256) void conv_kernel(ConvParams p) {
     const int tw = bid % p.tiles_w; bid /= p.tiles_w;
     const int th = bid % p.tiles_h;
     const int b = bid / p.tiles_h;
-    const int TW = p.TWB * 16;
-    const int h0 = th * p.TH, w0 = tw * TW, n0 = nt * 128;
+    const int TW = TWB * 16;
+    const int h0 = th * TH, w0 = tw * TW, n0 = nt * 128;
 
-    // this wave's four pixel blocks
-    int blk_r[4], blk_c[4];
+    float4_t acc[CONV_MB][4];
 #pragma unroll
-    for (int m = 0; m < 4; ++m) {
-        const int mb = wm * 4 + m;
-        blk_r[m] = mb / p.TWB;
-        blk_c[m] = (mb % p.TWB) * 16;
-    }
-
-    float4_t acc[4][4];
-#pragma unroll
-    for (int m = 0; m < 4; ++m)
+    for (int m = 0; m < CONV_MB; ++m)
 #pragma unroll
         for (int n = 0; n < 4; ++n) acc[m][n] = float4_t{0.f, 0.f, 0.f, 0.f};
 
+    // weight-tile staging plan: constant over the whole kernel
+    int b_lds[4], b_row[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int idx = u * CONV_NT + tid;
+        const int c = idx & 7, n = idx >> 3;
+        b_lds[u] = (n * 8 + (c ^ swz(n))) * 16;
+        b_row[u] = (n0 + n < n_out) ? (n0 + n) : -1;
+    }
+    int buf = 0;
+
     for (int s = 0; s < p.nseg; ++s) {
-        const Seg sg = p.seg[s];
-        const int PAD = (sg.kw / 2) * sg.dil;
-        const int PW = TW + 2 * PAD;
-        const int n_chunks_a = p.TH * PW * 8;
-        for (int i = 0; i < sg.kh; ++i) {
-            const int sy = sg.sgn * (i - sg.kh / 2) * sg.dil;
-            // all tile rows outside the image for this tap row -> nothing to add
-            if (h0 + sy + p.TH - 1 < 0 || h0 + sy >= p.H) continue;
-            for (int cc = 0; cc < sg.cin / BKE; ++cc) {
-                __syncthreads();  // previous compute has finished reading As / Bs
-                // ---- stage the input row patch: TH rows x PW columns x 128 B
-                for (int base = 0; base < n_chunks_a; base += 256 * 4) {
-                    uint4 v[4];
+        const Seg g = p.seg[s];
+        int padl, pw;
+        conv_geom(g.kw, g.dil, w0, TW, W, padl, pw);
+        const int n_chunks_a = TH * pw * 8;
+        const int ncc = g.cin / BKE;
+        // tap rows whose shifted tile touches the image form a contiguous range [i_lo, i_hi]
+        int i_lo = g.kh, i_hi = -1;
+        for (int i = 0; i < g.kh; ++i) {
+            const int sy = g.sgn * (i - g.kh / 2) * g.dil;
+            if (!(h0 + sy + TH - 1 < 0 || h0 + sy >= H)) { i_lo = min(i_lo, i); i_hi = max(i_hi, i); }
+        }
+        if (i_hi < i_lo) continue;
+        // Loads are buffer loads: a chunk outside the image (or a weight row beyond n_out) gets an
+        // offset beyond num_records and comes back as zeros - no branch around any load.
+        const long long xbytes = ((long long)(H * W - 1) * g.ld_x + g.cin) * ES;
+        const __amdgpu_buffer_rsrc_t rsrc_x = __builtin_amdgcn_make_buffer_rsrc(
+            (void*)(g.x + (long long)b * H * W * g.ld_x * ES), 0, (int)xbytes, 0x00020000);
+        const long long wbytes = ((long long)(g.kh * g.kw - 1) * g.w_tap_stride + (long long)n_out * g.cin) * ES;
+        const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc((void*)g.w, 0, (int)wbytes, 0x00020000);
+        int b_voff[4];
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        const int idx = base + u * 256 + tid;
-                        v[u] = make_uint4(0u, 0u, 0u, 0u);
-                        if (idx < n_chunks_a) {
-                            const int c = idx & 7, pix = idx >> 3;
-                            const int r = pix / PW, pc = pix - r * PW;
-                            const int hin = h0 + r + sy, win = w0 + pc - PAD;
-                            if (hin >= 0 && hin < p.H && win >= 0 && win < p.W) {
-                                const long long off =
-                                    ((long long)(b * p.H + hin) * p.W + win) * sg.ld_x + (long long)cc * BKE;
-                                v[u] = *reinterpret_cast<const uint4*>(sg.x + off * ES + c * 16);
-                            }
-                        }
-                    }
+        for (int u = 0; u < 4; ++u) b_voff[u] = b_row[u] >= 0 ? (b_row[u] * g.cin * ES + ((u * CONV_NT + tid) & 7) * 16) : -1;
+
+        uint4 regB[4];
+        auto load_b = [&](int i, int cc, int j) {
+            const int step_off = (int)(((long long)(i * g.kw + j) * g.w_tap_stride + cc * BKE) * ES);
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        const int idx = base + u * 256 + tid;
-                        if (idx < n_chunks_a) {
-                            const int c = idx & 7, pix = idx >> 3;
-                            const int pc = pix % PW;
-                            *reinterpret_cast<uint4*>(As + (pix * 8 + (c ^ swz(pc))) * 16) = v[u];
-                        }
-                    }
+            for (int u = 0; u < 4; ++u)
+                regB[u] = buf_load16(rsrc_w, b_voff[u] >= 0 ? (unsigned)(b_voff[u] + step_off) : BUF_OOB);
+        };
+        auto store_b = [&](int bsel) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) *reinterpret_cast<uint4*>(Bs + bsel * (128 * 128) + b_lds[u]) = regB[u];
+        };
+        auto stage_a = [&](int i, int cc) {     // TH rows x PW columns x 128 B, loads batched CONV_NA deep
+            const int sy = g.sgn * (i - g.kh / 2) * g.dil;
+            for (int base = 0; base < n_chunks_a; base += CONV_NA * CONV_NT) {
+                uint4 v[CONV_NA];
+                int dst[CONV_NA];
+#pragma unroll
+                for (int u = 0; u < CONV_NA; ++u) {
+                    const int idx = base + u * CONV_NT + tid;
+                    const int c = idx & 7, pix = idx >> 3;
+                    const int r = pix / pw, pc = pix - r * pw;
+                    const int hin = h0 + r + sy, win = w0 + pc - padl;
+                    const bool ok = idx < n_chunks_a && hin >= 0 && hin < H && win >= 0 && win < W;
+                    dst[u] = idx < n_chunks_a ? (pix * 8 + (c ^ swz(pc))) * 16 : -1;
+                    v[u] = buf_load16(rsrc_x, ok ? (unsigned)(((hin * W + win) * g.ld_x + cc * BKE) * ES + c * 16) : BUF_OOB);
                 }
-                for (int j = 0; j < sg.kw; ++j) {
-                    const int sx = sg.sgn * (j - sg.kw / 2) * sg.dil;
-                    if (j > 0) __syncthreads();  // previous tap has finished reading Bs
-                    // ---- stage the weight tile: 128 rows x 128 B
-                    {
-                        const char* wt = sg.w + ((long long)(i * sg.kw + j) * sg.w_tap_stride) * ES;
-                        uint4 v[4];
 #pragma unroll
-                        for (int u = 0; u < 4; ++u) {
-                            const int idx = u * 256 + tid;
-                            const int c = idx & 7, n = idx >> 3;
-                            v[u] = make_uint4(0u, 0u, 0u, 0u);
-                            if (n0 + n < p.n_out) {
-                                const long long off = (long long)(n0 + n) * sg.cin + (long long)cc * BKE;
-                                v[u] = *reinterpret_cast<const uint4*>(wt + off * ES + c * 16);
+                for (int u = 0; u < CONV_NA; ++u)
+                    if (dst[u] >= 0) *reinterpret_cast<uint4*>(As + dst[u]) = v[u];
+            }
+        };
+
+        for (int i = i_lo; i <= i_hi; ++i) {
+            const int sy = g.sgn * (i - g.kh / 2) * g.dil;
+            for (int cc = 0; cc < ncc; ++cc) {
+                // ---- group start: patch + first weight tile, synchronously
+                __syncthreads();                   // previous group is done with As and Bs[buf]
+                load_b(i, cc, 0);
+                stage_a(i, cc);
+                store_b(buf);
+                __syncthreads();
+                for (int j = 0; j < g.kw; ++j) {
+                    const int sx = g.sgn * (j - g.kw / 2) * g.dil;
+                    const bool more = j + 1 < g.kw;
+                    if (more) load_b(i, cc, j + 1);          // in flight while this tap computes
+                    // ---- 2 x (4 + 8 fragment reads, up to 32 MFMA)
+                    unsigned live = 0;
+#pragma unroll
+                    for (int m = 0; m < CONV_MB; ++m) {
+                        const int mb = wm * CONV_MB + m;
+                        const int h = h0 + mb / TWB, wc = w0 + (mb % TWB) * 16;
+                        const bool l = h < H && wc < W && h + sy >= 0 && h + sy < H && wc + sx + 15 >= 0 && wc + sx < W;
+                        live |= (l ? 1u : 0u) << m;
+                    }
+                    live = __builtin_amdgcn_readfirstlane(live);
+                    if (dbg & 2) live = 0;
+                    const char* Bc = Bs + buf * (128 * 128);
+                    if (live != 0u) {
+                        // ONE code path (two paths made hipcc keep two accumulator sets): fragment
+                        // reads are unconditional (a dead block reads pixel 0 of the patch), only
+                        // the MFMAs of a dead 16-pixel block are skipped, by a scalar branch.
+#pragma unroll
+                        for (int kk = 0; kk < 2; ++kk) {
+                            uint4 bf[4];
+#pragma unroll
+                            for (int n = 0; n < 4; ++n) {
+                                const int nl = wn * 64 + n * 16 + li;
+                                bf[n] = *reinterpret_cast<const uint4*>(Bc + (nl * 8 + ((kk * 4 + lg) ^ swz(nl))) * 16);
+                            }
+#pragma unroll
+                            for (int mh = 0; mh < 2; ++mh) {
+                                uint4 af[4];
+#pragma unroll
+                                for (int mq = 0; mq < 4; ++mq) {
+                                    const int m = mh * 4 + mq;
+                                    const int mb = wm * CONV_MB + m;
+                                    const bool l = (live >> m) & 1u;
+                                    const int pc = l ? padl + (mb % TWB) * 16 + sx + li : 0;
+                                    const int pix = l ? (mb / TWB) * pw + pc : 0;
+                                    af[mq] = *reinterpret_cast<const uint4*>(As + (pix * 8 + ((kk * 4 + lg) ^ swz(pc))) * 16);
+                                }
+#pragma unroll
+                                for (int mq = 0; mq < 4; ++mq) {
+                                    const int m = mh * 4 + mq;
+                                    if ((live >> m) & 1u) {
+#pragma unroll
+                                        for (int n = 0; n < 4; ++n) mma_frag<DT>(af[mq], bf[n], acc[m][n]);
+                                    }
+                                }
                             }
                         }
-#pragma unroll
-                        for (int u = 0; u < 4; ++u) {
-                            const int idx = u * 256 + tid;
-                            const int c = idx & 7, n = idx >> 3;
-                            *reinterpret_cast<uint4*>(Bs + (n * 8 + (c ^ swz(n))) * 16) = v[u];
-                        }
                     }
-                    __syncthreads();
-                    // ---- 2 x (4 + 4 fragment reads, 16 MFMA)
-                    bool live[4];
-#pragma unroll
-                    for (int m = 0; m < 4; ++m) {
-                        const int h = h0 + blk_r[m], wc = w0 + blk_c[m];
-                        live[m] = h < p.H && wc < p.W && h + sy >= 0 && h + sy < p.H && wc + sx + 15 >= 0 &&
-                                  wc + sx < p.W;
-                    }
-#pragma unroll
-                    for (int kk = 0; kk < 2; ++kk) {
-                        uint4 bf[4];
-#pragma unroll
-                        for (int n = 0; n < 4; ++n) {
-                            const int nl = wn * 64 + n * 16 + li;
-                            bf[n] = *reinterpret_cast<const uint4*>(Bs + (nl * 8 + ((kk * 4 + lg) ^ swz(nl))) * 16);
-                        }
-#pragma unroll
-                        for (int m = 0; m < 4; ++m) {
-                            if (!live[m]) continue;
-                            const int pc = PAD + blk_c[m] + sx + li;
-                            const int pix = blk_r[m] * PW + pc;
-                            const uint4 af =
-                                *reinterpret_cast<const uint4*>(As + (pix * 8 + ((kk * 4 + lg) ^ swz(pc))) * 16);
-#pragma unroll
-                            for (int n = 0; n < 4; ++n) mma_frag<DT>(af, bf[n], acc[m][n]);
-                        }
+                    if (more) {
+                        store_b(buf ^ 1);          // that half was last read one barrier ago
+                        __syncthreads();
+                        buf ^= 1;
                     }
                 }
             }
@@ -213,25 +274,26 @@ __global__ __launch_bounds__(256) void conv_kernel(ConvParams p) {
 
     // ---- epilogue: bias, ReLU, instance-norm moments, LDS-staged coalesced store
     __syncthreads();
-    TO* Cs = reinterpret_cast<TO*>(smem);  // [128 pixels][128 channels]
+    TO* Cs = reinterpret_cast<TO*>(smem);  // [256 pixels][128 channels]
     float ssum[4], ssq[4];
 #pragma unroll
     for (int n = 0; n < 4; ++n) {
         const int col = n0 + wn * 64 + n * 16 + li;
-        const float bv = (p.bias && col < p.n_out) ? p.bias[col] : 0.f;
+        const float bv = (p.bias && col < n_out) ? p.bias[col] : 0.f;
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-        for (int m = 0; m < 4; ++m) {
-            const int h = h0 + blk_r[m];
+        for (int m = 0; m < CONV_MB; ++m) {
+            const int mb = wm * CONV_MB + m;
+            const int h = h0 + mb / TWB;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int w = w0 + blk_c[m] + lg * 4 + r;
+                const int w = w0 + (mb % TWB) * 16 + lg * 4 + r;
                 float v = acc[m][n][r] + bv;
                 if (p.relu) v = fmaxf(v, 0.f);
-                if (!(h < p.H && w < p.W)) v = 0.f;
+                if (!(h < H && w < W)) v = 0.f;
                 s1 += v;
                 s2 += v * v;
-                const int ml = (wm * 4 + m) * 16 + lg * 4 + r;
+                const int ml = mb * 16 + lg * 4 + r;
                 store_from_f32(Cs + ml * 128 + wn * 64 + n * 16 + li, v);
             }
         }
@@ -245,27 +307,27 @@ __global__ __launch_bounds__(256) void conv_kernel(ConvParams p) {
             s1 += __shfl_xor(s1, 16, 64); s1 += __shfl_xor(s1, 32, 64);
             s2 += __shfl_xor(s2, 16, 64); s2 += __shfl_xor(s2, 32, 64);
             const int col = n0 + wn * 64 + n * 16 + li;
-            if (lg == 0 && col < p.n_out) {
-                atomicAdd(p.stats + ((long long)b * p.n_out + col) * 2 + 0, s1);
-                atomicAdd(p.stats + ((long long)b * p.n_out + col) * 2 + 1, s2);
+            if (lg == 0 && col < n_out) {
+                atomicAdd(p.stats + ((long long)b * n_out + col) * 2 + 0, s1);
+                atomicAdd(p.stats + ((long long)b * n_out + col) * 2 + 1, s2);
             }
         }
     }
     __syncthreads();
     constexpr int EPC = 16 / sizeof(TO);         // elements per 16-byte piece
     constexpr int PIECES = 128 / EPC;            // pieces per pixel row of the tile
-    for (int idx = tid; idx < 128 * PIECES; idx += 256) {
+    for (int idx = tid; idx < 256 * PIECES; idx += CONV_NT) {
         const int ml = idx / PIECES, pc = idx - ml * PIECES;
         const int mb = ml >> 4;
-        const int h = h0 + mb / p.TWB, w = w0 + (mb % p.TWB) * 16 + (ml & 15);
+        const int h = h0 + mb / TWB, w = w0 + (mb % TWB) * 16 + (ml & 15);
         const int col = n0 + pc * EPC;
-        if (h < p.H && w < p.W && col < p.n_out) {
-            TO* dst = reinterpret_cast<TO*>(p.out) + ((long long)(b * p.H + h) * p.W + w) * p.ld_out + col;
+        if (h < H && w < W && col < n_out) {
+            TO* dst = reinterpret_cast<TO*>(p.out) + ((long long)(b * H + h) * W + w) * p.ld_out + col;
             const TO* src = Cs + ml * 128 + pc * EPC;
-            if (col + EPC <= p.n_out && ((reinterpret_cast<uintptr_t>(dst) & 15) == 0)) {
+            if (col + EPC <= n_out && ((reinterpret_cast<uintptr_t>(dst) & 15) == 0)) {
                 *reinterpret_cast<uint4*>(dst) = *reinterpret_cast<const uint4*>(src);
             } else {
-                for (int e = 0; e < EPC && col + e < p.n_out; ++e) dst[e] = src[e];
+                for (int e = 0; e < EPC && col + e < n_out; ++e) dst[e] = src[e];
             }
         }
     }
@@ -437,7 +499,7 @@ int launch_conv(const ConvParams& p, size_t lds, hipStream_t stream) {
     const void* fn = (const void*)conv_kernel<DT, ODT>;
     if (lds > 64 * 1024) CUTIE_CHECK_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const long long grid = (long long)p.B * p.tiles_h * p.tiles_w * p.n_tiles_n;
-    hipLaunchKernelGGL((conv_kernel<DT, ODT>), dim3((unsigned)grid), dim3(256), lds, stream, p);
+    hipLaunchKernelGGL((conv_kernel<DT, ODT>), dim3((unsigned)grid), dim3(CONV_NT), lds, stream, p);
     CUTIE_CHECK_LAUNCH();
     return CUTIE_OK;
 }
@@ -463,7 +525,7 @@ extern "C" int cutie_conv_fwd(const cutie_conv_seg* segs, int n_segs, int B, int
     int twb = 1;
     while (twb < 8 && twb * 16 < W) twb *= 2;
     p.TWB = twb;
-    p.TH = 8 / twb;
+    p.TH = 16 / twb;      // 16 pixel blocks = 256 pixels per tile
     p.tiles_h = (int)cutie::cdiv(H, p.TH);
     p.tiles_w = (int)cutie::cdiv(W, twb * 16);
     p.n_tiles_n = (int)cutie::cdiv(n_out, 128);
@@ -478,19 +540,26 @@ extern "C" int cutie_conv_fwd(const cutie_conv_seg* segs, int n_segs, int B, int
         CUTIE_CHECK_ARG(g.ld_x >= g.cin && (g.ld_x * es) % 16 == 0 && cutie::aligned16(g.x) && cutie::aligned16(g.w),
                         "conv_fwd: segment %d needs 16-byte aligned rows (ld_x=%d)", s, g.ld_x);
         CUTIE_CHECK_ARG(g.w_tap_stride >= (int64_t)n_out * g.cin, "conv_fwd: segment %d w_tap_stride too small", s);
+        CUTIE_CHECK_ARG((int64_t)H * W * g.ld_x * es < (1ll << 31) && (int64_t)g.kh * g.kw * g.w_tap_stride * es < (1ll << 31),
+                        "conv_fwd: segment %d: one sample / one weight tensor must stay below 2 GiB (buffer addressing)", s);
         Seg& d = p.seg[s];
         d.x = (const char*)g.x; d.w = (const char*)g.w; d.w_tap_stride = g.w_tap_stride;
         d.ld_x = g.ld_x; d.cin = g.cin; d.kh = g.kh; d.kw = g.kw; d.dil = g.dil; d.sgn = g.flip ? -1 : 1;
-        const int pw = twb * 16 + 2 * (g.kw / 2) * g.dil;
+        const int tw_px = twb * 16;
+        int pad = (g.kw / 2) * g.dil;
+        const int pad_cap = (W > tw_px ? W - tw_px : 0) + 15;   // see conv_geom: halo clipped to the image + 15
+        if (pad > pad_cap) pad = pad_cap;
+        const int pw = tw_px + 2 * pad;
         const int bytes = p.TH * pw * 128;
         if (bytes > a_bytes) a_bytes = bytes;
     }
     p.a_bytes = a_bytes;
+    p.dbg = getenv("CUTIE_CONV_DBG") ? atoi(getenv("CUTIE_CONV_DBG")) : 0;
     p.B = B; p.H = H; p.W = W; p.n_out = n_out;
     p.out = (char*)out; p.ld_out = ld_out; p.bias = bias; p.relu = relu; p.stats = stats;
     const size_t oes = out_dtype == CUTIE_BF16 ? 2 : 4;
-    size_t lds = (size_t)a_bytes + 128 * 128;
-    if (lds < 128 * 128 * oes) lds = 128 * 128 * oes;
+    size_t lds = (size_t)a_bytes + 2 * 128 * 128;
+    if (lds < 256 * 128 * oes) lds = 256 * 128 * oes;
     CUTIE_CHECK_ARG(lds <= 160 * 1024, "conv_fwd: tile needs %zu B of LDS (dilation %d too large for W=%d)", lds,
                     segs[0].dil, W);
     CUTIE_CHECK_ARG((long long)B * p.tiles_h * p.tiles_w * p.n_tiles_n < (1ll << 31), "conv_fwd: grid too large");

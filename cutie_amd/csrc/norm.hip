@@ -181,11 +181,21 @@ __global__ __launch_bounds__(256) void in_bwd_apply_kernel(const TD* __restrict_
             storev<VEC>(dz + row * ld_dz + m.cl * VEC, o);
         }
     }
-    if (dbias) {
+    if (dbias) {   // per-(sample, channel) partials: B x fewer adders per address than dbias[c]
 #pragma unroll
         for (int e = 0; e < VEC; ++e) red[0][threadIdx.x][e] = sb[e];
-        block_reduce_atomic<VEC, 1>(red, m, CV, [&](int c, int) { return dbias + c; });
+        const int b = m.b;
+        block_reduce_atomic<VEC, 1>(red, m, CV, [&](int c, int) { return dbias + (int64_t)b * C + c; });
     }
+}
+
+__global__ __launch_bounds__(256) void sum_rows_kernel(const float* __restrict__ part, int B, int C,
+                                                       float* __restrict__ out, int accumulate) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float s = accumulate ? out[c] : 0.f;
+    for (int b = 0; b < B; ++b) s += part[(int64_t)b * C + c];
+    out[c] = s;
 }
 
 // one workgroup per (b, chunk of CV_BLK channel lanes): mean over HW, then broadcast
@@ -318,6 +328,14 @@ extern "C" int cutie_in_bwd_apply(const void* dy, int ld_dy, int dy_dtype, const
                                                 typename elem<ADT>::type>), g, dim3(256), 0, stream,
                            (const typename elem<DDT>::type*)dy, ld_dy, (const typename elem<ADT>::type*)a, ld_a,
                            stats, eps, red, relu, (typename elem<ADT>::type*)dz, ld_dz, dbias, HW, C))));
+    CUTIE_CHECK_LAUNCH();
+    return CUTIE_OK;
+}
+
+extern "C" int cutie_sum_rows(const float* part, int B, int C, float* out, int accumulate, cutie_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    CUTIE_CHECK_ARG(B >= 0 && C >= 1 && part && out, "sum_rows: bad arguments");
+    hipLaunchKernelGGL(sum_rows_kernel, dim3((C + 255) / 256), dim3(256), 0, stream, part, B, C, out, accumulate);
     CUTIE_CHECK_LAUNCH();
     return CUTIE_OK;
 }

@@ -148,11 +148,18 @@ def in_bwd_stats(dy, a, stats, red, eps=IN_EPS):
     return red
 
 
-def in_bwd_apply(dy, a, stats, red, dz, dbias=None, relu=True, eps=IN_EPS):
+def in_bwd_apply(dy, a, stats, red, dz, dbias_part=None, relu=True, eps=IN_EPS):
+    """dbias_part: f32 [B, C] zeroed partial sums (fold with sum_rows)."""
     B, HW, C = _bhwc(a)
     call("cutie_in_bwd_apply", ptr(dy), ld_of(dy), dt_of(dy), ptr(a), ld_of(a), dt_of(a), ptr(stats), eps,
-         ptr(red), 1 if relu else 0, ptr(dz), ld_of(dz), dt_of(dz), ptr(dbias), B, HW, C, stream())
+         ptr(red), 1 if relu else 0, ptr(dz), ld_of(dz), dt_of(dz), ptr(dbias_part), B, HW, C, stream())
     return dz
+
+
+def sum_rows(part, out, accumulate=False):
+    B, C = part.shape
+    call("cutie_sum_rows", ptr(part), B, C, ptr(out), 1 if accumulate else 0, stream())
+    return out
 
 
 def spatial_mean_bcast(x, out):

@@ -170,8 +170,8 @@ class Engine(object):
         P.convs = convs
         n_stats = sum(B * n.channels * 2 for n in convs)
         P.stats_all = torch.zeros(n_stats, dtype=torch.float32, device=dev)
-        P.red_all = torch.zeros(n_stats, dtype=torch.float32, device=dev)
-        P.a, P.stats, P.red, P.dz, P.dy = {}, {}, {}, {}, {}
+        P.red_all = torch.zeros(n_stats + n_stats // 2, dtype=torch.float32, device=dev)
+        P.a, P.stats, P.red, P.dz, P.dy, P.dbpart = {}, {}, {}, {}, {}, {}
         so = 0
         for n in convs:
             hs, ws = spatial(n)
@@ -179,6 +179,7 @@ class Engine(object):
             cnt = B * n.channels * 2
             P.stats[n.name] = P.stats_all[so:so + cnt].view(B, n.channels, 2)
             P.red[n.name] = P.red_all[so:so + cnt].view(B, n.channels, 2)
+            P.dbpart[n.name] = P.red_all[n_stats + so // 2:n_stats + (so + cnt) // 2].view(B, n.channels)
             so += cnt
         P.oob = torch.zeros(1, dtype=torch.int32, device=dev)
         P.bad = torch.zeros(1, dtype=torch.int32, device=dev)
@@ -350,7 +351,8 @@ class Engine(object):
                 av = P.a[n.name][..., :n.channels]
                 ops.in_bwd_stats(dy, av, P.stats[n.name], P.red[n.name])
                 ops.in_bwd_apply(dy, av, P.stats[n.name], P.red[n.name], P.dz[n.name][..., :n.channels],
-                                 dbias=self.grads[n.name + "/biases"], relu=True)
+                                 dbias_part=P.dbpart[n.name], relu=True)
+                ops.sum_rows(P.dbpart[n.name], self.grads[n.name + "/biases"])
                 src = n.inputs[0]
                 ops.conv_wgrad(P.view(src.name, a["cin"]), a["cin"], P.dz[n.name][..., :n.channels], n.channels,
                                a["kh"], a["kw"], a["rate"], self.grads[n.name + "/weights"], P.wgrad_ws)

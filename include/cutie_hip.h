@@ -141,8 +141,10 @@ int cutie_pack_weights(const float* w_hwio, int taps, int cin, int cout,
  * stats f32 [B][C][2] = (sum, sum of squares) over H*W as produced by cutie_conv_fwd.
  *   apply:     y = (a - mean) * rsqrt(var + eps)
  *   bwd_stats: red[b][c] = (sum dy, sum dy*xhat)           (caller-zeroed, f32 [B][C][2])
- *   bwd_apply: dz = [a > 0] * inv * (dy - red0/HW - xhat*red1/HW);  dbias[c] += sum dz
- *              (relu != 0 applies the ReLU mask of model_framework.py:173; dbias nullable)
+ *   bwd_apply: dz = [a > 0] * inv * (dy - red0/HW - xhat*red1/HW);  dbias_part[b][c] += sum_hw dz
+ *              (relu != 0 applies the ReLU mask of model_framework.py:173; dbias_part f32
+ *              [B][C], caller-zeroed, nullable; cutie_sum_rows folds it over b into d(biases)
+ *              in a fixed order)
  */
 int cutie_in_stats(const void* a, int ld_a, int a_dtype, int B, int HW, int C, float* stats,
                    cutie_stream_t stream);
@@ -153,8 +155,10 @@ int cutie_in_bwd_stats(const void* dy, int ld_dy, int dy_dtype, const void* a, i
                        int B, int HW, int C, cutie_stream_t stream);
 int cutie_in_bwd_apply(const void* dy, int ld_dy, int dy_dtype, const void* a, int ld_a,
                        int a_dtype, const float* stats, float eps, const float* red, int relu,
-                       void* dz, int ld_dz, int dz_dtype, float* dbias,
+                       void* dz, int ld_dz, int dz_dtype, float* dbias_part,
                        int B, int HW, int C, cutie_stream_t stream);
+/* out[c] (+)= sum over b of part[b][c] */
+int cutie_sum_rows(const float* part, int B, int C, float* out, int accumulate, cutie_stream_t stream);
 
 /* K8  Model.global_pool, model_framework.py:309-315: spatial mean broadcast back to HxW
  * (reduce_mean + nearest-neighbour resize), written into a channel slice. */

@@ -302,8 +302,10 @@ def test_instance_norm_fwd_bwd(ops, dt, C):
     red = torch.zeros((B, C, 2), dtype=torch.float32, device=DEV)
     ops.in_bwd_stats(dy.to(DEV), ad[..., :C], stats, red)
     dz = torch.zeros((B, H, W, ld), dtype=tdt, device=DEV)
-    db = torch.zeros((C,), dtype=torch.float32, device=DEV)
-    ops.in_bwd_apply(dy.to(DEV), ad[..., :C], stats, red, dz[..., :C], dbias=db, relu=True)
+    dbp = torch.zeros((B, C), dtype=torch.float32, device=DEV)
+    db = torch.full((C,), 4.0, dtype=torch.float32, device=DEV)
+    ops.in_bwd_apply(dy.to(DEV), ad[..., :C], stats, red, dz[..., :C], dbias_part=dbp, relu=True)
+    ops.sum_rows(dbp, db)
     tol = 1e-4 if dt == "f32" else 8e-3
     assert relerr(dz[..., :C], da_ref) < tol
     assert relerr(db, da_ref.sum(dim=(0, 1, 2))) < tol
