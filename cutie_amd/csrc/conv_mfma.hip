@@ -476,6 +476,195 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradParams p) {
             }
 }
 
+// ------------------------------------------------------------------------------------------
+// bf16 weight gradient, all kw column taps of one tap row per workgroup.
+//   workgroup = 512 lanes = 8 waves as 4 (cin) x 2 (cout); tile = 128 cin x 128 cout x kw taps;
+//   a wave owns 32 cin x 64 cout for every tap: kw x 2 x 4 accumulators (160 registers at kw=5).
+//   Per image row (64 pixels of K) one input row patch [halo + 64 + halo][128 cin] and one
+//   output-gradient row [64][128 cout] are staged; the kw taps read the SAME patch at shifted
+//   pixel rows through ds_read_b64_tr_b16, so the x operand costs 1/kw of a per-tap kernel.
+//   Rows r+1 are fetched into registers (buffer loads, zeros outside the image) while row r is
+//   multiplied, and land in the other half of a double-buffered LDS image: one barrier per row.
+constexpr int WG5_NT = 512;
+constexpr int WG5_KW = 5;      // at most 5 column taps
+constexpr int WG5_NX = 3;      // 16-byte chunks of the x row patch per lane (patch <= 96 pixels)
+constexpr int WG5_PIX = 64;    // pixels of K per stage
+
+struct Wgrad5Params {
+    const char* x;
+    const char* dz;
+    int ld_x, cin, ld_dz, cout;
+    int B, H, W, kh, kw, dil;
+    float* slabs;    // [splits][taps][cin][cout]
+    int splits, mt, ntile, nwseg, pad;   // pad = halo columns staged on each side (clipped)
+};
+
+__global__ __launch_bounds__(WG5_NT, 2) void wgrad5_kernel(Wgrad5Params p) {
+    constexpr int ES = 2;
+    constexpr int ROWB = 256;       // bytes per staged pixel row: 128 channels
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int pwx = WG5_PIX + 2 * p.pad;                    // staged pixel rows of the x patch
+    const int xbuf_bytes = pwx * ROWB, dbuf_bytes = WG5_PIX * ROWB;
+    char* Xs = smem;                                        // 2 x [pwx][128 ci]
+    char* Ds = smem + 2 * xbuf_bytes;                       // 2 x [64][128 co]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int li = lane & 15, lg = lane >> 4;
+    const int H = p.H, W = p.W, kw = p.kw, dil = p.dil, pad = p.pad;
+
+    int bid = blockIdx.x;
+    const int nt = bid % p.ntile; bid /= p.ntile;
+    const int mt = bid % p.mt;
+    const int ti = bid / p.mt;                 // tap row
+    const int sy = (ti - p.kh / 2) * dil;
+    const int m0 = mt * 128, n0 = nt * 128;
+
+    const int units_total = p.B * H * p.nwseg;  // a unit = (sample, image row, 64-pixel column segment)
+    const int per = (units_total + p.splits - 1) / p.splits;
+    const int unit_begin = blockIdx.y * per;
+    const int unit_end = min(units_total, unit_begin + per);
+
+    float4_t acc[WG5_KW][2][4];
+#pragma unroll
+    for (int t = 0; t < WG5_KW; ++t)
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int n = 0; n < 4; ++n) acc[t][m][n] = float4_t{0.f, 0.f, 0.f, 0.f};
+
+    const long long xbytes = ((long long)(p.B * H * W - 1) * p.ld_x + p.cin) * ES;
+    const long long dbytes = ((long long)(p.B * H * W - 1) * p.ld_dz + p.cout) * ES;
+    const __amdgpu_buffer_rsrc_t rsrc_x = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (int)xbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_d = __builtin_amdgcn_make_buffer_rsrc((void*)p.dz, 0, (int)dbytes, 0x00020000);
+
+    // staging plan: lane -> (pixel row r0 + 32u, 16-byte chunk c of 8 channels); 512 lanes cover
+    // 32 pixel rows x 16 chunks per pass, and the swizzle ignores bit 5 of the row, so one LDS
+    // offset serves every pass
+    const int sc = tid & 15, r0 = tid >> 4;
+    const int st_lds = r0 * ROWB + (((sc >> 1) ^ tr_func(r0)) * 32) + (sc & 1) * 16;
+    const int x_ch = (m0 + sc * 8 < p.cin) ? (m0 + sc * 8) : -1;
+    const int d_ch = (n0 + sc * 8 < p.cout) ? (n0 + sc * 8) : -1;
+
+    uint4 regX[WG5_NX], regD[2];
+    // unit -> (b, h, ws); returns false when the shifted input row is outside the image
+    auto decode = [&](int unit, int& b, int& h, int& ws) {
+        const int seg = unit % p.nwseg;
+        const int row = unit / p.nwseg;
+        b = row / H;
+        h = row - b * H;
+        ws = seg * WG5_PIX;
+        const int hh = h + sy;
+        return hh >= 0 && hh < H;
+    };
+    auto load_unit = [&](int b, int h, int ws) {
+        const int hh = h + sy;
+#pragma unroll
+        for (int u = 0; u < WG5_NX; ++u) {
+            const int pr = r0 + 32 * u;
+            const int w = ws - pad + pr;
+            const bool ok = pr < pwx && x_ch >= 0 && w >= 0 && w < W;
+            regX[u] = buf_load16(rsrc_x, ok ? (unsigned)((((b * H + hh) * W + w) * p.ld_x + x_ch) * ES) : BUF_OOB);
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int w = ws + r0 + 32 * u;
+            const bool ok = d_ch >= 0 && w < W;
+            regD[u] = buf_load16(rsrc_d, ok ? (unsigned)((((b * H + h) * W + w) * p.ld_dz + d_ch) * ES) : BUF_OOB);
+        }
+    };
+    auto store_unit = [&](int bsel) {
+#pragma unroll
+        for (int u = 0; u < WG5_NX; ++u)
+            if (r0 + 32 * u < pwx) *reinterpret_cast<uint4*>(Xs + bsel * xbuf_bytes + st_lds + u * 32 * ROWB) = regX[u];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) *reinterpret_cast<uint4*>(Ds + bsel * dbuf_bytes + st_lds + u * 32 * ROWB) = regD[u];
+    };
+    // next unit at or after `u` whose input row is inside the image
+    auto seek = [&](int u, int& b, int& h, int& ws) {
+        while (u < unit_end && !decode(u, b, h, ws)) ++u;
+        return u;
+    };
+
+    int cb, ch, cws;
+    int cur = seek(unit_begin, cb, ch, cws);
+    int buf = 0;
+    if (cur < unit_end) {
+        load_unit(cb, ch, cws);
+        store_unit(0);
+    }
+    __syncthreads();
+    const int q = li >> 2, pp = li & 3;
+    while (cur < unit_end) {
+        int nb, nh, nws;
+        const int nxt = seek(cur + 1, nb, nh, nws);
+        if (nxt < unit_end) load_unit(nb, nh, nws);          // in flight while this row is multiplied
+        const char* Xc = Xs + buf * xbuf_bytes;
+        const char* Dc = Ds + buf * dbuf_bytes;
+#pragma unroll 1
+        for (int ks = 0; ks < WG5_PIX / 32; ++ks) {
+            const int px0 = cws + ks * 32;                   // first output pixel of this K block
+            if (px0 >= W) continue;
+            const int r1 = ks * 32 + lg * 8 + q, r2 = r1 + 4;
+            short8_t bf[4];
+#pragma unroll
+            for (int n = 0; n < 4; ++n) {
+                const int blk = wn * 4 + n;
+                const short4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                    (__attribute__((address_space(3))) short4_t*)(Dc + r1 * ROWB + ((blk ^ tr_func(r1)) * 32) + pp * 8));
+                const short4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                    (__attribute__((address_space(3))) short4_t*)(Dc + r2 * ROWB + ((blk ^ tr_func(r2)) * 32) + pp * 8));
+                bf[n] = short8_t{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            }
+#pragma unroll
+            for (int t = 0; t < WG5_KW; ++t) {
+                if (t >= kw) break;
+                const int sx = (t - kw / 2) * dil;
+                // input pixels px0+sx .. px0+sx+31 all outside the image: nothing to add (uniform)
+                if (px0 + sx + 31 < 0 || px0 + sx >= W) continue;
+                const int x1 = pad + sx + r1, x2 = x1 + 4;   // patch pixel rows
+                short8_t af[2];
+#pragma unroll
+                for (int m = 0; m < 2; ++m) {
+                    const int blk = wm * 2 + m;
+                    const short4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                        (__attribute__((address_space(3))) short4_t*)(Xc + x1 * ROWB + ((blk ^ tr_func(x1)) * 32) + pp * 8));
+                    const short4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                        (__attribute__((address_space(3))) short4_t*)(Xc + x2 * ROWB + ((blk ^ tr_func(x2)) * 32) + pp * 8));
+                    af[m] = short8_t{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                }
+#pragma unroll
+                for (int m = 0; m < 2; ++m)
+#pragma unroll
+                    for (int n = 0; n < 4; ++n)
+                        acc[t][m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[m], bf[n], acc[t][m][n], 0, 0, 0);
+            }
+        }
+        if (nxt < unit_end) store_unit(buf ^ 1);             // that half was last read one barrier ago
+        __syncthreads();
+        buf ^= 1;
+        cur = nxt; cb = nb; ch = nh; cws = nws;
+    }
+
+#pragma unroll
+    for (int t = 0; t < WG5_KW; ++t) {
+        if (t >= kw) break;
+        float* slab = p.slabs + ((long long)blockIdx.y * p.kh * kw + (ti * kw + t)) * p.cin * p.cout;
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int n = 0; n < 4; ++n)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int ci = m0 + (wm * 2 + m) * 16 + lg * 4 + r;
+                    const int co = n0 + (wn * 4 + n) * 16 + li;
+                    if (ci < p.cin && co < p.cout) slab[(long long)ci * p.cout + co] = acc[t][m][n][r];
+                }
+    }
+}
+
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slabs, int splits, long long n,
                                                            float* __restrict__ dw, int accumulate) {
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
@@ -483,6 +672,15 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
         for (int k = 0; k < splits; ++k) s += slabs[(long long)k * n + i];
         dw[i] = s;
     }
+}
+
+inline int wgrad5_splits(int B, int H, int W, int cin, int cout, int kh) {
+    const long long groups = (long long)kh * cutie::cdiv(cin, 128) * cutie::cdiv(cout, 128);
+    long long s = 256 / groups;                 // about one 512-lane workgroup per CU
+    const long long units = (long long)B * H * cutie::cdiv(W, WG5_PIX);
+    if (s > units) s = units;
+    if (s < 1) s = 1;
+    return (int)s;
 }
 
 inline int wgrad_splits(int B, int H, int cin, int cout, int taps) {
@@ -571,9 +769,12 @@ extern "C" int cutie_conv_fwd(const cutie_conv_seg* segs, int n_segs, int B, int
     return launch_conv<CUTIE_F32, CUTIE_F32>(p, lds, stream);
 }
 
-extern "C" size_t cutie_conv_wgrad_workspace_bytes(int B, int H, int /*W*/, int cin, int cout, int kh, int kw) {
-    if (B < 1 || H < 1 || cin < 1 || cout < 1 || kh < 1 || kw < 1) return 0;
-    return (size_t)wgrad_splits(B, H, cin, cout, kh * kw) * kh * kw * cin * cout * sizeof(float);
+extern "C" size_t cutie_conv_wgrad_workspace_bytes(int B, int H, int W, int cin, int cout, int kh, int kw) {
+    if (B < 1 || H < 1 || W < 1 || cin < 1 || cout < 1 || kh < 1 || kw < 1) return 0;
+    int s = wgrad_splits(B, H, cin, cout, kh * kw);
+    const int s5 = wgrad5_splits(B, H, W, cin, cout, kh);
+    if (s5 > s) s = s5;
+    return (size_t)s * kh * kw * cin * cout * sizeof(float);
 }
 
 extern "C" int cutie_conv_wgrad(const void* x, int ld_x, int cin, const void* dz, int ld_dz, int cout, int B, int H,
@@ -600,6 +801,40 @@ extern "C" int cutie_conv_wgrad(const void* x, int ld_x, int cin, const void* dz
     if (!workspace || workspace_bytes < need) {
         cutie::set_error("conv_wgrad: workspace %zu < %zu", workspace_bytes, need);
         return CUTIE_E_WORKSPACE;
+    }
+    const long long n_w = (long long)kh * kw * cin * cout;
+    long long g_red = cutie::cdiv(n_w, 256);
+    if (g_red > 4096) g_red = 4096;
+    if (dtype == CUTIE_BF16 && kw <= WG5_KW && (long long)B * H * W * (ld_x > ld_dz ? ld_x : ld_dz) * es < (1ll << 31)) {
+        Wgrad5Params q;
+        q.x = (const char*)x; q.dz = (const char*)dz; q.ld_x = ld_x; q.cin = cin; q.ld_dz = ld_dz; q.cout = cout;
+        q.B = B; q.H = H; q.W = W; q.kh = kh; q.kw = kw; q.dil = dil;
+        q.slabs = (float*)workspace;
+        q.splits = wgrad5_splits(B, H, W, cin, cout, kh);
+        q.mt = (int)cutie::cdiv(cin, 128);
+        q.ntile = (int)cutie::cdiv(cout, 128);
+        q.nwseg = (int)cutie::cdiv(W, WG5_PIX);
+        // halo columns: with one 64-pixel segment per row everything beyond the image is zero
+        // padding and a live 32-pixel K block reaches at most |shift| mod 32 columns outside
+        int pad = 0;
+        for (int t = 0; t < kw; ++t) {
+            int sx = (t - kw / 2) * dil;
+            if (sx < 0) sx = -sx;
+            const int need = q.nwseg == 1 ? sx % 32 : sx;
+            if (need > pad) pad = need;
+        }
+        q.pad = pad;
+        const int pwx = WG5_PIX + 2 * pad;
+        if (pwx * 16 <= WG5_NX * WG5_NT) {
+            const size_t lds5 = (size_t)2 * (pwx + WG5_PIX) * 256;
+            CUTIE_CHECK_HIP(hipFuncSetAttribute((const void*)wgrad5_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds5));
+            hipLaunchKernelGGL(wgrad5_kernel, dim3(kh * q.mt * q.ntile, q.splits), dim3(WG5_NT), lds5, stream, q);
+            CUTIE_CHECK_LAUNCH();
+            hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)g_red), dim3(256), 0, stream, (const float*)workspace,
+                               q.splits, n_w, dw, accumulate);
+            CUTIE_CHECK_LAUNCH();
+            return CUTIE_OK;
+        }
     }
     WgradParams p;
     p.x = (const char*)x; p.dz = (const char*)dz; p.ld_x = ld_x; p.cin = cin; p.ld_dz = ld_dz; p.cout = cout;
