@@ -56,7 +56,6 @@ struct ConvParams {
     float* stats;
     int TH, TWB, tiles_h, tiles_w, n_tiles_n;
     int a_bytes;  // LDS bytes reserved for the A patch
-    int dbg;
 };
 
 template <int DT> struct Traits;
@@ -117,8 +116,7 @@ __global__ __launch_bounds__(CONV_NT, 2) void conv_kernel(ConvParams p) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
     const int li = lane & 15, lg = lane >> 4;
-    const int H = p.H, W = p.W, TH = p.TH, TWB = p.TWB, n_out = p.n_out, dbg = p.dbg;
-    if (dbg & 128) return;
+    const int H = p.H, W = p.W, TH = p.TH, TWB = p.TWB, n_out = p.n_out;
 
     // workgroup -> (sample, tile row, tile col, channel tile); channel tile fastest
     int bid = blockIdx.x;
@@ -225,7 +223,6 @@ __global__ __launch_bounds__(CONV_NT, 2) void conv_kernel(ConvParams p) {
                         live |= (l ? 1u : 0u) << m;
                     }
                     live = __builtin_amdgcn_readfirstlane(live);
-                    if (dbg & 2) live = 0;
                     const char* Bc = Bs + buf * (128 * 128);
                     if (live != 0u) {
                         // ONE code path (two paths made hipcc keep two accumulator sets): fragment
@@ -752,7 +749,6 @@ extern "C" int cutie_conv_fwd(const cutie_conv_seg* segs, int n_segs, int B, int
         if (bytes > a_bytes) a_bytes = bytes;
     }
     p.a_bytes = a_bytes;
-    p.dbg = getenv("CUTIE_CONV_DBG") ? atoi(getenv("CUTIE_CONV_DBG")) : 0;
     p.B = B; p.H = H; p.W = W; p.n_out = n_out;
     p.out = (char*)out; p.ld_out = ld_out; p.bias = bias; p.relu = relu; p.stats = stats;
     const size_t oes = out_dtype == CUTIE_BF16 ? 2 : 4;

@@ -329,9 +329,13 @@ class Engine(object):
         if bad:
             raise CutieError("%d labels fall outside [0, %d) (entity_class_id overflow, SURVEY.md 0.6)" % (bad, self.C))
 
-    def loss_backward(self, P):
+    def loss_backward(self, P, on_ready=None):
         """model_cutie.py:107-140 + tf.gradients: fills grads_flat (incl. the L2 term) and the
-        squared global norm the way tf.clip_by_global_norm sees it.  Needs forward(labels=...)."""
+        squared global norm the way tf.clip_by_global_norm sees it.  Needs forward(labels=...).
+
+        on_ready(upto): data-parallel hook.  The flat gradient buffer is laid out in backward
+        order, so after each conv's weight gradient (and its L2 term) the prefix [0, upto) is
+        final; the caller starts that slice's all-reduce while earlier layers still compute."""
         if not P.has_labels:
             raise CutieError("loss_backward needs forward(..., labels=...)")
         self._plan_backward(P)
@@ -342,6 +346,8 @@ class Engine(object):
         ops.softmax_ce_bwd(P.probs, P.labels, P.weight, C, P.dy[lname][..., :C])
         self.grads_flat.zero_()
         P.red_all.zero_()
+        P.reg.zero_()
+        wd = float(spec["weight_decay"])
         for n in reversed(net.nodes):
             if n.op == "conv":
                 a = n.attrs
@@ -356,13 +362,16 @@ class Engine(object):
                 src = n.inputs[0]
                 ops.conv_wgrad(P.view(src.name, a["cin"]), a["cin"], P.dz[n.name][..., :n.channels], n.channels,
                                a["kh"], a["kw"], a["rate"], self.grads[n.name + "/weights"], P.wgrad_ws)
+                if on_ready is not None:
+                    off, cnt, _ = self.offsets[n.name + "/weights"]
+                    ops.l2_add(self.params_flat[off:off + cnt], self.grads_flat[off:off + cnt], wd, P.reg, P.scratch)
+                    on_ready(_pad(off + cnt, 64))
             elif n.op == "embed":
                 ops.conv_fwd(self._grad_segments(P, n.name), P.dy[n.name], n.channels)
                 ops.embed_bwd(P.grid, P.dy[n.name][..., :n.channels], self.grads[n.name + "/weights"])
                 P.d_embed = P.dy[n.name]
-        P.reg.zero_()
-        ops.l2_add(self.params_flat[:self.n_conv_w], self.grads_flat[:self.n_conv_w], float(spec["weight_decay"]),
-                   P.reg, P.scratch)
+        if on_ready is None:
+            ops.l2_add(self.params_flat[:self.n_conv_w], self.grads_flat[:self.n_conv_w], wd, P.reg, P.scratch)
         return P
 
     def global_norm_sq(self, P, tf_indexed_slices=True):

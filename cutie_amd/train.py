@@ -41,11 +41,13 @@ class Trainer(object):
         P = eng.forward(batch["grid_table"], labels=batch["gt_classes"])
         if self.check_inputs:
             eng.check_inputs(P)
-        eng.loss_backward(P)
         if self.buckets is not None:
-            # TODO(next): call buckets.ready() from inside backward as each wgrad lands
-            self.buckets.ready(eng.n_conv_w)
+            # each bucket's all-reduce starts as soon as backward has finished its slice and runs
+            # on the collective's stream under the remaining layers' dgrad/wgrad kernels
+            eng.loss_backward(P, on_ready=self.buckets.ready)
             self.buckets.finish()
+        else:
+            eng.loss_backward(P)
         gn = eng.global_norm_sq(P, tf_indexed_slices=(self.world == 1))
         self.t += 1
         lr_t = self.lr * math.sqrt(1.0 - self.b2 ** self.t) / (1.0 - self.b1 ** self.t)

@@ -293,6 +293,15 @@ def main():
         for tc in (True, False):
             loader.text_case = tc
             loader.tokenizer = tok_cased if tc else tok_uncased
+            # the loader maps numeric characters to '0' before splitting (:892-895): the vocab
+            # subset must also cover the substrings of those strings
+            mapped = "".join("0" if ref.is_number(c) else c for c in (t if tc else t.lower()))
+            for b in loader.tokenizer.basic_tokenizer.tokenize(mapped):
+                for s in range(len(b)):
+                    for e in range(s + 1, len(b) + 1):
+                        sub = b[s:e] if s == 0 else "##" + b[s:e]
+                        if sub in tok_cased.vocab:
+                            needed.add(sub)
             before = dict(loader.dictionary)
             dressed.append({"text": t, "text_case": tc, "out": loader._dress_text(t, False)})
             loader.dictionary = before

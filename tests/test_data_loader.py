@@ -1,0 +1,274 @@
+"""Host-side mirror of the reference loader against golden vectors that
+the reference's own data_loader_json.py / tokenization.py produced (tests/golden/make_golden.py).
+The GPU part (row a2 through DataLoader._positional_mapping -> cutie_grid_build) is marked gpu."""
+import hashlib
+import json
+import os
+import random
+import shutil
+import types
+
+import numpy as np
+import pytest
+
+from cutie_amd import dictfile, tokenization
+from cutie_amd.data_loader_json import DataLoader, is_number
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _load(name):
+    with open(os.path.join(GOLD, name), encoding="utf-8") as f:
+        return json.load(f)
+
+
+@pytest.fixture(scope="module")
+def tok_fix():
+    return _load("tokenizer_cases.json")
+
+
+@pytest.fixture(scope="module")
+def workdir(tmp_path_factory, tok_fix):
+    """dict/vocab.txt + dict/20000T_* (the subsets the fixture carries) + two copies of the sample
+    document, laid out like the reference's working directory."""
+    root = tmp_path_factory.mktemp("loader")
+    os.makedirs(root / "dict")
+    os.makedirs(root / "invoice_data")
+    with open(root / "dict" / "vocab.txt", "w", encoding="utf-8") as f:
+        f.write("\n".join(tok_fix["vocab_subset"]) + "\n")
+    w2i = dict(tok_fix["word_to_index_subset"])
+    dictfile.save_npy_dict(str(root / "dict" / "20000T_dictionary.npy"), {w: 1 for w in w2i})
+    dictfile.save_npy_dict(str(root / "dict" / "20000T_word_to_index.npy"), w2i)
+    dictfile.save_npy_dict(str(root / "dict" / "20000T_index_to_word.npy"), {i: w for w, i in w2i.items()})
+    for k in (0, 1):
+        shutil.copy(os.path.join(GOLD, "invoice", "Faktura1.pdf_0.json"),
+                    root / "invoice_data" / ("Faktura1.pdf_%d.json" % k))
+    return root
+
+
+def make_params(root, **over):
+    p = types.SimpleNamespace(
+        doc_path=str(root / "invoice_data"), test_path=str(root / "no_such_dir"), use_cutie2=False,
+        text_case=True, tokenize=True, load_dict_from_path=str(root / "dict" / "20000T"),
+        dict_path=str(root / "dict" / "20000T"), vocab_file=str(root / "dict" / "vocab.txt"),
+        rows_segment=72, cols_segment=72, augment_strategy=1, positional_mapping_strategy=1,
+        rows_target=64, cols_target=64, rows_ulimit=80, cols_ulimit=80, fill_bbox=False,
+        data_augmentation_extra=True, data_augmentation_dropout=1,
+        data_augmentation_extra_rows=16, data_augmentation_extra_cols=16, batch_size=1, save_dict=False)
+    for k, v in over.items():
+        setattr(p, k, v)
+    return p
+
+
+@pytest.fixture(scope="module")
+def loader(workdir):
+    return DataLoader(make_params(workdir), update_dict=False, load_dictionary=True, data_split=0.75,
+                      verbose=False)
+
+
+# ------------------------------------------------------------------------------ tokenizer
+def test_tokenizer_matches_reference_outputs(tok_fix, workdir):
+    toks = {False: tokenization.FullTokenizer(str(workdir / "dict" / "vocab.txt"), do_lower_case=False),
+            True: tokenization.FullTokenizer(str(workdir / "dict" / "vocab.txt"), do_lower_case=True)}
+    assert len(tok_fix["cases"]) > 200
+    for c in tok_fix["cases"]:
+        tk = toks[c["lower"]]
+        assert tk.basic_tokenizer.tokenize(c["text"]) == c["basic"], c["text"]
+        assert tk.tokenize(c["text"]) == c["pieces"], c["text"]
+
+
+def test_wordpiece_edge_cases(workdir):
+    tk = tokenization.FullTokenizer(str(workdir / "dict" / "vocab.txt"), do_lower_case=False)
+    assert tk.tokenize("") == []
+    assert tk.tokenize(" \t\n") == []
+    assert tk.tokenize("x" * 201) == ["[UNK]"]                  # > 200 characters
+    assert tk.basic_tokenizer.tokenize("a\x00b�c") == ["abc"]   # NUL / U+FFFD dropped
+    assert tk.basic_tokenizer.tokenize("a b") == ["a", "b"]     # Zs is a blank
+    ids = tk.convert_tokens_to_ids(["[UNK]"])
+    assert tk.convert_ids_to_tokens(ids) == ["[UNK]"]
+
+
+def test_is_number():
+    assert is_number("7") and is_number("1e3") and is_number("½") and is_number("٣")
+    assert not is_number("a") and not is_number("") and not is_number("1,5") and not is_number("½½")
+
+
+def test_dress_text_matches_reference(tok_fix, loader, workdir):
+    toks = {True: tokenization.FullTokenizer(str(workdir / "dict" / "vocab.txt"), do_lower_case=False),
+            False: tokenization.FullTokenizer(str(workdir / "dict" / "vocab.txt"), do_lower_case=True)}
+    saved = (loader.text_case, loader.tokenizer, dict(loader.dictionary))
+    try:
+        for c in tok_fix["dress_text"]:
+            loader.text_case = c["text_case"]
+            loader.tokenizer = toks[c["text_case"]]
+            assert loader._dress_text(c["text"], False) == c["out"], (c["text"], c["text_case"])
+    finally:
+        loader.text_case, loader.tokenizer, loader.dictionary = saved
+
+
+def test_dress_text_update_dict_adds_and_counts(loader):
+    saved = dict(loader.dictionary)
+    try:
+        loader.dictionary.pop("zz9", None)
+        out = loader._dress_text("[UNK]", False)
+        n0 = loader.dictionary["[UNK]"]
+        loader._dress_text("中", False)      # a CJK character outside the vocab subset
+        assert loader.dictionary["[UNK]"] == n0 + 1
+        assert out
+    finally:
+        loader.dictionary = saved
+
+
+def test_dress_bbox(loader):
+    assert loader._dress_bbox([10, 20, 110, 60]) == (10, 20, 110, 60)
+    assert loader._dress_bbox([[5, 7], [40, 6], [41, 30], [4, 31]]) == (4, 6, 41, 31)     # quadrilateral
+    assert loader._dress_bbox([-3.5, -1, 9.9, 8.2]) == (0, 0, 9, 8)                      # clamp + truncation
+
+
+# ------------------------------------------------------------------------------ a1: _collect_data
+def test_collect_data_matches_reference(loader):
+    gold = _load("faktura1_items.json")
+    assert loader.num_classes == gold["num_classes"] and loader.classes == gold["classes"]
+    for split, docs in (("training", loader.training_docs), ("validation", loader.validation_docs)):
+        assert len(docs) == len(gold["docs"][split])
+        for doc, gdoc in zip(docs, gold["docs"][split]):
+            assert len(doc) == len(gdoc) == 366
+            for item, g in zip(doc, gdoc):
+                assert item[0] == g["file_name"] and item[1] == g["text"] and item[2] == g["word_id"]
+                assert [int(v) for v in item[3]] == g["box"]
+                assert [int(v) for v in item[4]] == g["extent"]
+                assert (item[5], item[6]) == (g["max_rows"], g["max_cols"]) == (42, 63)
+                assert loader.word_to_index[item[1]] == g["dict_id"]
+                assert loader._dress_class(item[0], item[2], loader.training_labels) == (g["entity_id"], g["class_id"])
+    assert loader.training_labels == gold["labels"]
+
+
+def test_collect_data_skips_special_and_empty(loader):
+    content = [{"id": 1, "bbox": [], "text": "x"}, {"id": 2, "bbox": [0, 0, 10, 10], "text": "*"},
+               {"id": 3, "bbox": [0, 0, 10, 10], "text": "="}, {"id": 4, "bbox": [20, 5, 60, 15], "text": "-"}]
+    saved = dict(loader.dictionary)
+    try:
+        (doc,) = loader._collect_data("f.jpg", content, False)
+    finally:
+        loader.dictionary = saved
+    assert len(doc) == 1 and doc[0][2] == 4
+    assert doc[0][4] == [18, 3, 62, 17] and doc[0][5:] == [1, 1]
+
+
+def test_natural_cols_grows_until_every_line_fits(loader):
+    # five boxes on one text line, all centred in the same place: 5 columns are needed
+    boxes = [(100, 10, 120, 20)] * 5
+    assert loader._natural_cols(boxes, (0, 0, 200, 30), 1, 1) == 5
+    # spread evenly they need no more than their count either
+    boxes = [(40 * i, 10, 40 * i + 30, 20) for i in range(5)]
+    assert loader._natural_cols(boxes, (-2, 8, 192, 22), 1, 1) <= 5
+
+
+def test_segment_grid_splits_wide_documents(workdir):
+    ld = DataLoader(make_params(workdir, segment_grid=True, cols_segment=40), update_dict=False,
+                    load_dictionary=True, data_split=0.75, verbose=False)
+    # natural 63 columns > 40: the document is offered as a left and a right part of 40+ columns
+    docs = ld.training_docs + ld.validation_docs
+    assert len(docs) == 4
+    assert {d[0][6] for d in docs} == {40}
+    assert all(d[0][5] == 42 for d in docs)
+    assert len(docs[0]) + len(docs[1]) >= 366
+
+
+# ------------------------------------------------------------------------------ a3: shapes
+def test_cal_rows_cols_matches_reference(loader):
+    gold = _load("shapes.json")
+    assert [loader.rows, loader.cols] == gold["loader_rows_cols"]
+    docs = loader.training_docs + loader.validation_docs
+    assert [[d[0][5], d[0][6]] for d in docs] == gold["natural"]
+    random.seed(7)
+    for rec in gold["augment_strategy1"]:
+        out = loader._cal_rows_cols(loader.training_docs, extra_augmentation=True)
+        assert list(out) == rec["out"]
+    assert loader._cal_rows_cols(loader.training_docs) == (42, 63, 42, 63)
+    loader.augment_strategy = 9
+    try:
+        with pytest.raises(Exception, match="unknown augment strategy"):
+            loader._cal_rows_cols(loader.training_docs, extra_augmentation=True)
+    finally:
+        loader.augment_strategy = 1
+
+
+def test_pack_documents(loader):
+    gold = _load("faktura1_items.json")["docs"]["training"][0]
+    tok_box, tok_id, tok_ecid, tok_cls, extent, doc_off = loader.pack_documents(loader.training_docs, loader.training_labels)
+    assert doc_off.tolist() == [0, 366] and extent.tolist() == [gold[0]["extent"]]
+    assert tok_box.tolist() == [g["box"] for g in gold]
+    assert tok_id.tolist() == [g["dict_id"] for g in gold]
+    assert tok_ecid.tolist() == [g["entity_id"] * 18 + g["class_id"] for g in gold]
+    assert tok_cls.tolist() == [g["class_id"] for g in gold]
+
+
+def test_strategy2_is_refused(workdir):
+    ld = DataLoader(make_params(workdir, positional_mapping_strategy=2), update_dict=False,
+                    load_dictionary=True, verbose=False)
+    with pytest.raises(NotImplementedError):
+        ld._positional_mapping(ld.training_docs, ld.training_labels, 64, 64)
+
+
+def test_dictionary_round_trip(workdir, tmp_path):
+    """ctor with save_dict writes files the reader takes back (data_loader_json.py:107-110)"""
+    for f in os.listdir(workdir / "dict"):
+        shutil.copy(workdir / "dict" / f, tmp_path / f)
+    p = make_params(workdir, save_dict=True, load_dict_from_path=str(tmp_path / "20000T"))
+    ld = DataLoader(p, update_dict=False, load_dictionary=True, verbose=False)
+    d, w2i, i2w = dictfile.load_dictionary_triplet(str(tmp_path / "20000T"))
+    assert w2i == ld.word_to_index and d == ld.dictionary and i2w == ld.index_to_word
+    assert dictfile.load_npy_classes(str(tmp_path / "20000T_classes.npy")) == ld.classes
+
+
+# ------------------------------------------------------------------------------ a2 through the loader (GPU)
+def _sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("key", ["r64c64s1", "r64c64s0", "r42c63s1", "r80c80s1", "r64c32s1", "r48c20s0", "r48c20s1"])
+def test_positional_mapping_on_gpu_matches_reference(loader, key):
+    meta = _load("faktura1_grids.json")[key]
+    if "error" in meta:
+        pytest.skip("the reference itself fails on this shape")
+    npz = np.load(os.path.join(GOLD, "faktura1_grids.npz"))
+    loader.pm_strategy = meta["strategy"]
+    try:
+        out = loader._positional_mapping(loader.training_docs, loader.training_labels, meta["rows"], meta["cols"])
+    finally:
+        loader.pm_strategy = 1
+    grid, lab, bboxes, label_mapids, bbox_mapids, file_names, cols, psx, psy = out
+    assert np.array(grid).shape == (1, meta["rows"], meta["cols"], 1)
+    assert np.array_equal(np.array(grid)[..., 0], npz[key + "_grid"])
+    assert np.array_equal(np.array(lab), npz[key + "_labels"])
+    assert np.array_equal(np.array(psx), npz[key + "_ps_x"]) and np.array_equal(np.array(psy), npz[key + "_ps_y"])
+    assert _sha(np.array(grid)[..., 0].astype(np.int32)) == meta["grid_sha256"]
+    assert label_mapids == meta["label_mapids"]
+    assert [{int(k): v for k, v in m.items()} for m in bbox_mapids] == \
+           [{int(k): v for k, v in m.items()} for m in meta["bbox_mapids"]]
+    assert file_names == meta["file_names"] and cols == meta["updated_cols"]
+
+
+@pytest.mark.gpu
+def test_next_batch_and_fetch_on_gpu(workdir):
+    import torch
+    ld = DataLoader(make_params(workdir, batch_size=1), update_dict=False, load_dictionary=True, verbose=False)
+    random.seed(3)
+    b = ld.next_batch()
+    rows, cols = b["shape"]
+    assert 42 <= rows <= 80 and 63 <= cols <= 80
+    assert b["grid_table"].shape == (1, rows, cols, 1) and b["grid_table"].dtype == np.int32
+    assert b["gt_classes"].shape == (1, rows, cols) and b["gt_classes"].dtype == np.int8
+    assert b["data_image"].size == 0 and b["ps_1d_indices"].size == 0
+    assert set(b) >= {"grid_table", "gt_classes", "data_image", "ps_1d_indices", "bboxes", "label_mapids",
+                      "bbox_mapids", "file_name", "shape"}
+    dev = b["device"]
+    assert dev["grid_table"].is_cuda and torch.equal(dev["grid_table"].cpu(), torch.from_numpy(b["grid_table"]))
+    assert (b["grid_table"] != 0).sum() == 366
+    v = ld.fetch_validation_data()
+    assert v["shape"] == [64, 64]
+    npz = np.load(os.path.join(GOLD, "faktura1_grids.npz"))
+    assert np.array_equal(v["grid_table"][0, ..., 0], npz["r64c64s1_grid"])
+    assert ld.fetch_test_data() is None
