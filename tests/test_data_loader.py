@@ -241,7 +241,7 @@ def test_positional_mapping_on_gpu_matches_reference(loader, key):
         loader.pm_strategy = 1
     grid, lab, bboxes, label_mapids, bbox_mapids, file_names, cols, psx, psy = out
     assert np.array(grid).shape == (1, meta["rows"], meta["cols"], 1)
-    assert np.array_equal(np.array(grid)[..., 0], npz[key + "_grid"])
+    assert np.array_equal(np.array(grid), npz[key + "_grid"].reshape(1, meta["rows"], meta["cols"], 1))
     assert np.array_equal(np.array(lab), npz[key + "_labels"])
     assert np.array_equal(np.array(psx), npz[key + "_ps_x"]) and np.array_equal(np.array(psy), npz[key + "_ps_y"])
     assert _sha(np.array(grid)[..., 0].astype(np.int32)) == meta["grid_sha256"]
@@ -270,5 +270,5 @@ def test_next_batch_and_fetch_on_gpu(workdir):
     v = ld.fetch_validation_data()
     assert v["shape"] == [64, 64]
     npz = np.load(os.path.join(GOLD, "faktura1_grids.npz"))
-    assert np.array_equal(v["grid_table"][0, ..., 0], npz["r64c64s1_grid"])
+    assert np.array_equal(v["grid_table"], npz["r64c64s1_grid"].reshape(1, 64, 64, 1))
     assert ld.fetch_test_data() is None
