@@ -174,7 +174,7 @@ def main():
             peak = BF16_PEAK_TFLOPS if args.dtype == "bf16" else 157.3
             out["roofline"] = {"bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
                                "frac": round(ach / peak, 4), "traffic": None,
-                               "kernel": "conv_kernel (forward + data-gradient implicit GEMM)", "launches": n,
+                               "kernel": "conv_wide_kernel + conv_kernel (forward + data-gradient implicit GEMM)", "launches": n,
                                "avg_launch_ms": round(ms / max(n, 1), 4),
                                "share_of_step": round(ms / (1e3 * dt), 4)}
         if not args.no_cpu_baseline and world == 1:

@@ -11,7 +11,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libcutie_hip.so")
-SOURCES = ["core.hip", "grid_build.hip", "embed.hip", "norm.hip", "loss.hip", "optim.hip", "conv_mfma.hip"]
+SOURCES = ["core.hip", "grid_build.hip", "embed.hip", "norm.hip", "loss.hip", "optim.hip", "conv_mfma.hip", "conv_wide.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-function"]
 
@@ -24,7 +24,8 @@ def _stale(out, deps):
 
 
 def build(force=False, verbose=True):
-    hdrs = [os.path.join(CSRC, "common.h"), os.path.join(HERE, "..", "include", "cutie_hip.h")]
+    hdrs = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "conv_common.h"),
+            os.path.join(HERE, "..", "include", "cutie_hip.h")]
     objs = []
     procs = []
     for src in SOURCES:

@@ -1,0 +1,66 @@
+// Shared by conv_mfma.hip (general kernel) and conv_wide.hip (256-channel-tile kernel).
+#pragma once
+#include "common.h"
+
+namespace cutie {
+namespace convk {
+
+typedef __attribute__((ext_vector_type(8))) short short8_t;
+typedef __attribute__((ext_vector_type(4))) short short4_t;
+typedef __attribute__((ext_vector_type(4))) float float4_t;
+
+struct Seg {
+    const char* x;
+    const char* w;
+    long long w_tap_stride;  // elements
+    int ld_x, cin, kh, kw, dil, sgn;
+};
+
+struct ConvParams {
+    Seg seg[CUTIE_MAX_SEGS];
+    int nseg;
+    int B, H, W, n_out;
+    char* out;
+    int ld_out;
+    const float* bias;
+    int relu;
+    float* stats;
+    int TH, TWB, tiles_h, tiles_w, n_tiles_n;
+    int a_bytes;  // LDS bytes reserved for the A patch
+};
+
+template <int DT> struct Traits;
+template <> struct Traits<CUTIE_BF16> { static constexpr int ES = 2; static constexpr int BKE = 64; };
+template <> struct Traits<CUTIE_F32> { static constexpr int ES = 4; static constexpr int BKE = 32; };
+
+__device__ __forceinline__ int swz(int row) { return (row >> 1) & 7; }
+
+template <int DT>
+__device__ __forceinline__ void mma_frag(const uint4& a, const uint4& b, float4_t& c) {
+    if constexpr (DT == CUTIE_BF16) {
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(short8_t, a), __builtin_bit_cast(short8_t, b), c,
+                                                    0, 0, 0);
+    } else {
+        c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.x), __uint_as_float(b.x), c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.y), __uint_as_float(b.y), c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.z), __uint_as_float(b.z), c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.w), __uint_as_float(b.w), c, 0, 0, 0);
+    }
+}
+
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
+constexpr unsigned BUF_OOB = 0x80000000u;   // beyond any num_records: the buffer load returns zeros
+
+__device__ __forceinline__ uint4 buf_load16(__amdgpu_buffer_rsrc_t rsrc, unsigned voff) {
+    const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)voff, 0, 0);
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
+
+
+}  // namespace convk
+
+// conv_wide.hip: bf16 in / bf16 out, n_out a multiple of 256, every segment cin a multiple of 64
+int launch_conv_wide(const convk::ConvParams& p, hipStream_t stream);
+bool conv_wide_supported(const convk::ConvParams& p);
+
+}  // namespace cutie

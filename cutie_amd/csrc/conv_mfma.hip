@@ -28,54 +28,12 @@
 //   read) out of row-major [pixel][channel] LDS images; f32 uses plain ds_read_b32.
 //   K is split over row groups into f32 slabs, summed by wgrad_reduce_kernel in a fixed order
 //   (deterministic, no float atomics).
-#include "common.h"
+#include "conv_common.h"
 #include <stdlib.h>
 
 namespace {
 using namespace cutie;
-
-typedef __attribute__((ext_vector_type(8))) short short8_t;
-typedef __attribute__((ext_vector_type(4))) short short4_t;
-typedef __attribute__((ext_vector_type(4))) float float4_t;
-
-struct Seg {
-    const char* x;
-    const char* w;
-    long long w_tap_stride;  // elements
-    int ld_x, cin, kh, kw, dil, sgn;
-};
-
-struct ConvParams {
-    Seg seg[CUTIE_MAX_SEGS];
-    int nseg;
-    int B, H, W, n_out;
-    char* out;
-    int ld_out;
-    const float* bias;
-    int relu;
-    float* stats;
-    int TH, TWB, tiles_h, tiles_w, n_tiles_n;
-    int a_bytes;  // LDS bytes reserved for the A patch
-};
-
-template <int DT> struct Traits;
-template <> struct Traits<CUTIE_BF16> { static constexpr int ES = 2; static constexpr int BKE = 64; };
-template <> struct Traits<CUTIE_F32> { static constexpr int ES = 4; static constexpr int BKE = 32; };
-
-__device__ __forceinline__ int swz(int row) { return (row >> 1) & 7; }
-
-template <int DT>
-__device__ __forceinline__ void mma_frag(const uint4& a, const uint4& b, float4_t& c) {
-    if constexpr (DT == CUTIE_BF16) {
-        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(short8_t, a), __builtin_bit_cast(short8_t, b), c,
-                                                    0, 0, 0);
-    } else {
-        c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.x), __uint_as_float(b.x), c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.y), __uint_as_float(b.y), c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.z), __uint_as_float(b.z), c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.w), __uint_as_float(b.w), c, 0, 0, 0);
-    }
-}
+using namespace cutie::convk;
 
 constexpr int CONV_NT = 256;     // lanes per workgroup: 4 waves as 2 (pixel halves) x 2 (channel halves)
 constexpr int CONV_MB = 8;       // 16-pixel blocks per wave: a wave owns 128 pixels x 64 channels
@@ -88,14 +46,6 @@ __device__ __forceinline__ void conv_geom(int kw, int dil, int w0, int TW, int W
     padl = min(pad, w0 + 15);
     const int padr = max(0, min(pad, W + 15 - (w0 + TW)));
     pw = padl + TW + padr;
-}
-
-typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
-constexpr unsigned BUF_OOB = 0x80000000u;   // beyond any num_records: the buffer load returns zeros
-
-__device__ __forceinline__ uint4 buf_load16(__amdgpu_buffer_rsrc_t rsrc, unsigned voff) {
-    const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)voff, 0, 0);
-    return make_uint4(v.x, v.y, v.z, v.w);
 }
 
 // Workgroup tile = 256 pixels (TH rows x TWB*16 columns of one sample) x 128 output channels.
@@ -757,6 +707,18 @@ extern "C" int cutie_conv_fwd(const cutie_conv_seg* segs, int n_segs, int B, int
     CUTIE_CHECK_ARG(lds <= 160 * 1024, "conv_fwd: tile needs %zu B of LDS (dilation %d too large for W=%d)", lds,
                     segs[0].dil, W);
     CUTIE_CHECK_ARG((long long)B * p.tiles_h * p.tiles_w * p.n_tiles_n < (1ll << 31), "conv_fwd: grid too large");
+    // wide layers: 256-pixel x 256-channel tiles fed by LDS-DMA (conv_wide.hip)
+    static const bool wide_on = !(getenv("CUTIE_CONV_WIDE") && atoi(getenv("CUTIE_CONV_WIDE")) == 0);
+    if (wide_on && dtype == CUTIE_BF16 && out_dtype == CUTIE_BF16 && cutie::conv_wide_supported(p)) {
+        ConvParams q = p;
+        int th = 16, tcb = 1;
+        while (th > 1 && th / 2 >= H && tcb * 16 < W) { th /= 2; tcb *= 2; }
+        q.TH = th; q.TWB = tcb;
+        q.tiles_h = (int)cutie::cdiv(H, th);
+        q.tiles_w = (int)cutie::cdiv(W, tcb * 16);
+        q.n_tiles_n = n_out / 256;
+        if ((long long)B * q.tiles_h * q.tiles_w * q.n_tiles_n < (1ll << 31)) return cutie::launch_conv_wide(q, stream);
+    }
     if (dtype == CUTIE_BF16) {
         if (out_dtype == CUTIE_BF16) return launch_conv<CUTIE_BF16, CUTIE_BF16>(p, lds, stream);
         return launch_conv<CUTIE_BF16, CUTIE_F32>(p, lds, stream);

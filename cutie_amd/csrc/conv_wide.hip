@@ -1,0 +1,293 @@
+// K2w: forward / data-gradient convolution for the wide layers (bf16, n_out a multiple of 256),
+// built like a 256 x 256 GEMM tile with an asynchronous two-stage LDS ring.
+//
+// Same contract as conv_kernel in conv_mfma.hip (tf.nn.conv2d / atrous_conv2d + bias + ReLU of
+// /root/reference/model_framework.py:168-204,414-422 and their input gradients); what differs is
+// how the operands reach the matrix cores:
+//   * workgroup = 512 lanes = 8 waves as 2 (pixel halves) x 4 (channel quarters); tile = 256
+//     pixels (TH rows x TWB*16 columns of one sample; 16 x 16 for the 64 x 64 grid) x 256 output
+//     channels; a wave owns 128 x 64 = 8 x 4 accumulators of v_mfma_f32_16x16x32_bf16;
+//   * one K step = (tap, 64 input channels).  Its A tile (256 shifted pixels x 128 B) and B tile
+//     (256 weight rows x 128 B) go global -> LDS by `buffer_load_dwordx4 ... lds` (no registers,
+//     no ds_write): each lane's SOURCE address carries the tap shift, the XOR swizzle and the
+//     zero padding (an out-of-range offset makes the hardware write zeros), the LDS image is
+//     lane-linear.  Step s+1 is in flight while step s computes (2 x 64 KB of LDS);
+//   * one barrier per K step: wait for my own loads, barrier (everybody's loads have landed and
+//     everybody is done reading the other buffer), issue the next step's loads, compute;
+//   * a tap whose shifted tile lies wholly outside the image is not a step at all (uniform for
+//     the workgroup), which keeps the in-bounds FLOP accounting for 16-aligned dilations.
+#include "conv_common.h"
+
+namespace cutie {
+namespace {
+using namespace cutie::convk;
+
+constexpr int CW_NT = 512;
+constexpr int CW_A0 = 0, CW_B0 = 65536, CW_BUF = 32768;    // LDS map: A0 A1 B0 B1, 32 KB each
+constexpr int CW_LDS = 131072;
+
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef unsigned u32x4s_t __attribute__((ext_vector_type(4)));
+
+// raw buffer descriptor (stride 0, 32-bit records): base, base_hi, num_records, flags
+__device__ __forceinline__ u32x4s_t make_rsrc(const void* base, unsigned bytes) {
+    const unsigned long long a = reinterpret_cast<unsigned long long>(base);
+    u32x4s_t r;
+    r.x = __builtin_amdgcn_readfirstlane((unsigned)a);
+    r.y = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32) & 0xffffu);
+    r.z = __builtin_amdgcn_readfirstlane(bytes);
+    r.w = 0x00020000u;
+    return r;
+}
+
+// `buffer_load_dwordx4 ... lds`: 64 lanes x 16 B land at LDS byte address lds_dst + 16*lane; each
+// lane's source offset is its own.  Written as inline asm so that hipcc does not put a
+// `s_waitcnt vmcnt(0)` in front of every later ds_read (it cannot tell the two LDS buffers
+// apart); the pipeline's own counted wait + barrier order the data.  M0 is saved and restored.
+__device__ __forceinline__ void glds16(u32x4s_t rsrc, unsigned lds_dst, unsigned voff) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(voff), "s"(rsrc), "s"(lds_dst)
+                 : "memory");
+}
+
+__global__ __launch_bounds__(CW_NT) void conv_wide_kernel(ConvParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    const int li = lane & 15, lg = lane >> 4;
+    const unsigned lds0 = (unsigned)(uintptr_t)((lds_void_t*)smem);
+    const int H = p.H, W = p.W, TCB = p.TWB, n_out = p.n_out;
+    const int TR = p.TH, TC = TCB * 16;
+
+    // consecutive block ids go round-robin over the 8 XCDs: give each XCD a contiguous run of
+    // tiles so that neighbouring tiles (shared halos) meet in one L2
+    int bid = blockIdx.x;
+    const int nwg = gridDim.x;
+    if ((nwg & 7) == 0) bid = (bid & 7) * (nwg >> 3) + (bid >> 3);
+    const int nt = bid % p.n_tiles_n; bid /= p.n_tiles_n;
+    const int tw = bid % p.tiles_w; bid /= p.tiles_w;
+    const int th = bid % p.tiles_h;
+    const int b = bid / p.tiles_h;
+    const int h0 = th * TR, w0 = tw * TC, n0 = nt * 256;
+
+    float4_t acc[8][4];
+#pragma unroll
+    for (int m = 0; m < 8; ++m)
+#pragma unroll
+        for (int n = 0; n < 4; ++n) acc[m][n] = float4_t{0.f, 0.f, 0.f, 0.f};
+
+    // staging plan: wave w moves 1-KB pieces 4w..4w+3 of the A tile and of the B tile; lane l of
+    // a piece is (row = l >> 3, 16-byte slot = l & 7) and fetches chunk slot ^ swz(row)
+    int a_h[4], a_w[4], a_c16[4], b_row[4], b_c16[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int r = wave * 32 + k * 8 + (lane >> 3);     // tile pixel / weight row 0..255
+        const int mb = r >> 4;
+        a_h[k] = h0 + mb / TCB;
+        a_w[k] = w0 + (mb % TCB) * 16 + (r & 15);
+        a_c16[k] = ((lane & 7) ^ swz(r)) * 16;
+        b_row[k] = n0 + r;
+        b_c16[k] = a_c16[k];
+    }
+    // fragment read offsets (bytes from the A / B tile base); + m*2048 / n*2048 per 16-row block
+    int a_rd[2], b_rd[2];
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+        const int c16 = ((kk * 4 + lg) ^ ((li >> 1) & 7)) * 16;
+        a_rd[kk] = (wm * 128 + li) * 128 + c16;
+        b_rd[kk] = (wn * 64 + li) * 128 + c16;
+    }
+    int buf = 0;
+
+    for (int s = 0; s < p.nseg; ++s) {
+        const Seg g = p.seg[s];
+        const int ncc = g.cin >> 6;
+        // taps whose shifted tile touches the image
+        unsigned live = 0;
+        for (int i = 0; i < g.kh; ++i) {
+            const int sy = g.sgn * (i - g.kh / 2) * g.dil;
+            if (h0 + sy + TR - 1 < 0 || h0 + sy >= H) continue;
+            for (int j = 0; j < g.kw; ++j) {
+                const int sx = g.sgn * (j - g.kw / 2) * g.dil;
+                if (w0 + sx + TC - 1 < 0 || w0 + sx >= W) continue;
+                live |= 1u << (i * g.kw + j);
+            }
+        }
+        live = __builtin_amdgcn_readfirstlane(live);
+        if (live == 0u) continue;
+
+        const long long xbytes = ((long long)(H * W - 1) * g.ld_x + g.cin) * 2;
+        const u32x4s_t rsrc_x = make_rsrc(g.x + (long long)b * H * W * g.ld_x * 2, (unsigned)xbytes);
+        const long long wbytes = ((long long)(g.kh * g.kw - 1) * g.w_tap_stride + (long long)n_out * g.cin) * 2;
+        const u32x4s_t rsrc_w = make_rsrc(g.w, (unsigned)wbytes);
+        int a_base[4];
+        unsigned b_base[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            a_base[k] = (a_h[k] * W + a_w[k]) * g.ld_x * 2 + a_c16[k];
+            b_base[k] = b_row[k] < n_out ? (unsigned)(b_row[k] * g.cin * 2 + b_c16[k]) : BUF_OOB;
+        }
+
+        // one step's loads: 4 A pieces + 4 B pieces per wave.  `piece` 0..7 so that the pipelined
+        // loop can drop one piece between MFMA groups instead of a burst after the barrier.
+        int da = 0, sy = 0, sx = 0;
+        unsigned db = 0;
+        auto step_offsets = [&](int tap, int cc) {
+            const int i = tap / g.kw, j = tap - i * g.kw;
+            sy = g.sgn * (i - g.kh / 2) * g.dil;
+            sx = g.sgn * (j - g.kw / 2) * g.dil;
+            da = ((sy * W + sx) * g.ld_x + cc * 64) * 2;
+            db = (unsigned)(((long long)tap * g.w_tap_stride + cc * 64) * 2);
+        };
+        auto issue_piece = [&](int piece, int bsel) {
+            if (piece < 4) {
+                const int k = piece;
+                const bool ok = (unsigned)(a_h[k] + sy) < (unsigned)H && (unsigned)(a_w[k] + sx) < (unsigned)W;
+                glds16(rsrc_x, lds0 + CW_A0 + bsel * CW_BUF + wave * 4096 + k * 1024,
+                       ok ? (unsigned)(a_base[k] + da) : BUF_OOB);
+            } else {
+                const int k = piece - 4;    // an out-of-range weight row stays out of range after + db
+                glds16(rsrc_w, lds0 + CW_B0 + bsel * CW_BUF + wave * 4096 + k * 1024, b_base[k] + db);
+            }
+        };
+        auto compute = [&](int bsel, auto prefetch) {
+            const char* At = smem + CW_A0 + bsel * CW_BUF;
+            const char* Bt = smem + CW_B0 + bsel * CW_BUF;
+            uint4 bf0[4], af0[8], bf1[4], af1[8];
+#pragma unroll
+            for (int n = 0; n < 4; ++n) bf0[n] = *reinterpret_cast<const uint4*>(Bt + b_rd[0] + n * 2048);
+#pragma unroll
+            for (int m = 0; m < 8; ++m) af0[m] = *reinterpret_cast<const uint4*>(At + a_rd[0] + m * 2048);
+            // first K half: between the groups of 4 MFMAs, one 1-KB piece of the next step's tiles
+            // is sent on its way and the second half's fragments are fetched; the scheduling
+            // barriers keep hipcc from gathering the loads into one burst
+#pragma unroll
+            for (int m = 0; m < 8; ++m) {
+                prefetch(m);
+                if (m == 3) {
+#pragma unroll
+                    for (int n = 0; n < 4; ++n) bf1[n] = *reinterpret_cast<const uint4*>(Bt + b_rd[1] + n * 2048);
+                }
+                if (m >= 4) {
+                    af1[2 * (m - 4)] = *reinterpret_cast<const uint4*>(At + a_rd[1] + (2 * (m - 4)) * 2048);
+                    af1[2 * (m - 4) + 1] = *reinterpret_cast<const uint4*>(At + a_rd[1] + (2 * (m - 4) + 1) * 2048);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int n = 0; n < 4; ++n) mma_frag<CUTIE_BF16>(af0[m], bf0[n], acc[m][n]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int m = 0; m < 8; ++m)
+#pragma unroll
+                for (int n = 0; n < 4; ++n) mma_frag<CUTIE_BF16>(af1[m], bf1[n], acc[m][n]);
+        };
+
+        // ---- software pipeline over the live (tap, channel chunk) steps of this segment
+        unsigned rest = live;
+        int tap = __builtin_ctz(rest);
+        rest &= rest - 1;
+        int cc = 0;
+        __builtin_amdgcn_s_barrier();        // the previous segment's last reads of `buf` are done
+        step_offsets(tap, cc);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) issue_piece(q, buf);
+        while (true) {
+            // taps innermost: consecutive steps read the same 128-byte channel chunk of
+            // overlapping pixels, so the A lines are still in L2 (with channels innermost the
+            // reuse distance is 4 steps x ~1 MB per XCD - the whole L2)
+            int ntap, nc = cc;
+            bool more = true;
+            if (rest != 0u) {
+                ntap = __builtin_ctz(rest);
+                rest &= rest - 1;
+            } else {
+                nc = cc + 1;
+                more = nc < ncc;
+                rest = live;
+                ntap = __builtin_ctz(rest);
+                rest &= rest - 1;
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            if (!more) break;
+            step_offsets(ntap, nc);
+            const int nb = buf ^ 1;
+            compute(buf, [&](int m) { issue_piece(m, nb); });
+            tap = ntap;
+            cc = nc;
+            buf = nb;
+        }
+        compute(buf, [&](int) {});
+        buf ^= 1;
+    }
+
+    // ---- epilogue: bias, ReLU, instance-norm moments, LDS-staged coalesced store
+    __syncthreads();
+    bf16_t* Cs = reinterpret_cast<bf16_t*>(smem);  // [256 pixels][256 channels]
+#pragma unroll
+    for (int n = 0; n < 4; ++n) {
+        const int cl = wn * 64 + n * 16 + li;
+        const int col = n0 + cl;
+        const float bv = (p.bias && col < n_out) ? p.bias[col] : 0.f;
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int m = 0; m < 8; ++m) {
+            const int mb = wm * 8 + m;
+            const int h = h0 + mb / TCB;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int w = w0 + (mb % TCB) * 16 + lg * 4 + r;
+                float v = acc[m][n][r] + bv;
+                if (p.relu) v = fmaxf(v, 0.f);
+                if (!(h < H && w < W)) v = 0.f;
+                s1 += v;
+                s2 += v * v;
+                Cs[(mb * 16 + lg * 4 + r) * 256 + cl] = f2bf(v);
+            }
+        }
+        if (p.stats) {
+            s1 += __shfl_xor(s1, 16, 64); s1 += __shfl_xor(s1, 32, 64);
+            s2 += __shfl_xor(s2, 16, 64); s2 += __shfl_xor(s2, 32, 64);
+            if (lg == 0 && col < n_out) {
+                atomicAdd(p.stats + ((long long)b * n_out + col) * 2 + 0, s1);
+                atomicAdd(p.stats + ((long long)b * n_out + col) * 2 + 1, s2);
+            }
+        }
+    }
+    __syncthreads();
+    for (int idx = tid; idx < 256 * 32; idx += CW_NT) {      // 16-byte pieces: 32 per pixel row
+        const int ml = idx >> 5, pc = idx & 31;
+        const int mb = ml >> 4;
+        const int h = h0 + mb / TCB, w = w0 + (mb % TCB) * 16 + (ml & 15);
+        const int col = n0 + pc * 8;
+        if (h < H && w < W && col < n_out) {
+            bf16_t* dst = reinterpret_cast<bf16_t*>(p.out) + ((long long)(b * H + h) * W + w) * p.ld_out + col;
+            *reinterpret_cast<uint4*>(dst) = *reinterpret_cast<const uint4*>(Cs + ml * 256 + pc * 8);
+        }
+    }
+}
+
+}  // namespace
+
+bool conv_wide_supported(const ConvParams& p) {
+    if (p.n_out % 256 != 0 || (p.ld_out * 2) % 16 != 0 || !aligned16(p.out)) return false;
+    for (int s = 0; s < p.nseg; ++s)
+        if (p.seg[s].cin % 64 != 0 || p.seg[s].kh * p.seg[s].kw > 32) return false;
+    return true;
+}
+
+// p.TH / p.TWB / tiles_* / n_tiles_n must describe 256-pixel x 256-channel tiles
+int launch_conv_wide(const ConvParams& p, hipStream_t stream) {
+    CUTIE_CHECK_HIP(hipFuncSetAttribute((const void*)conv_wide_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, CW_LDS));
+    const long long grid = (long long)p.B * p.tiles_h * p.tiles_w * p.n_tiles_n;
+    hipLaunchKernelGGL(conv_wide_kernel, dim3((unsigned)grid), dim3(CW_NT), CW_LDS, stream, p);
+    CUTIE_CHECK_LAUNCH();
+    return CUTIE_OK;
+}
+
+}  // namespace cutie

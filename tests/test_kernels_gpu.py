@@ -214,6 +214,70 @@ def test_conv_bf16_out_and_no_relu(ops, dt):
     assert relerr(out, ref) < 6e-3     # one bf16 rounding of the output
 
 
+WIDE_CASES = [
+    # B, H, W, cin, cout, kh, kw, dil  -- bf16 in / bf16 out with cout % 256 == 0: the LDS-DMA kernel
+    (2, 64, 64, 64, 256, 3, 5, 1),
+    (1, 64, 64, 128, 256, 3, 5, 16),
+    (1, 32, 64, 64, 256, 3, 5, 8),
+    (1, 42, 63, 64, 256, 3, 5, 4),
+    (1, 7, 80, 192, 512, 3, 5, 2),
+    (3, 16, 16, 320, 256, 1, 1, 1),
+    (1, 5, 130, 64, 256, 3, 3, 2),
+]
+
+
+@pytest.mark.parametrize("case", WIDE_CASES)
+def test_conv_wide_bf16(ops, case):
+    from cutie_amd import capi
+    B, H, W, cin, cout, kh, kw, dil = case
+    g = torch.Generator().manual_seed(hash(case) % 1000 + 7)
+    x = _rand_act(g, (B, H, W, cin), torch.bfloat16)
+    w = (torch.randn((kh, kw, cin, cout), generator=g) * 0.05).bfloat16().float()
+    bias = torch.randn(cout, generator=g) * 0.1
+    ref_a = torch.relu(co.conv_raw(x.double(), w.double(), dil) + bias.double())
+    wf, _ = ops.pack_weights(w.to(DEV), capi.BF16)
+    ld_out = cout + 8
+    out = torch.full((B, H, W, ld_out), 3.0, dtype=torch.bfloat16, device=DEV)
+    stats = torch.zeros((B, cout, 2), dtype=torch.float32, device=DEV)
+    xd = torch.zeros((B, H, W, cin + 64), dtype=torch.bfloat16, device=DEV)
+    xd[..., 32:32 + cin] = x.to(DEV)
+    ops.conv_fwd([dict(x=xd[..., 32:32 + cin], w=wf, cin=cin, kh=kh, kw=kw, dil=dil)], out[..., :cout], cout,
+                 bias=bias.to(DEV), relu=True, stats=stats)
+    torch.cuda.synchronize()
+    assert relerr(out[..., :cout], ref_a) < 6e-3            # one bf16 rounding of the output
+    # against the bf16-rounded reference the only differences are last-bit rounding flips
+    assert (out[..., :cout].float().cpu() - ref_a.float().bfloat16().float()).abs().max() < 0.07
+    assert torch.all(out[..., cout:] == 3.0)
+    ref_s = torch.stack([ref_a.sum(dim=(1, 2)), (ref_a ** 2).sum(dim=(1, 2))], dim=-1)
+    assert relerr(stats, ref_s) < 2e-3
+
+
+def test_conv_wide_dgrad_multi_segment(ops):
+    """data gradient of a 256-channel tensor consumed by a 3x5 dil 4 conv (256 outputs), a 3x5
+    dil 16 conv (256 outputs) and channels [256:512) of a 1x1 conv over a 768-channel concat."""
+    from cutie_amd import capi
+    g = torch.Generator().manual_seed(19)
+    B, H, W, C = 1, 32, 64, 256
+    w1 = (torch.randn((3, 5, C, 256), generator=g) * 0.03).bfloat16().float()
+    w2 = (torch.randn((3, 5, C, 256), generator=g) * 0.03).bfloat16().float()
+    w3 = (torch.randn((1, 1, 768, 128), generator=g) * 0.03).bfloat16().float()
+    dz1 = _rand_act(g, (B, H, W, 256), torch.bfloat16)
+    dz2 = _rand_act(g, (B, H, W, 256), torch.bfloat16)
+    dz3 = _rand_act(g, (B, H, W, 128), torch.bfloat16)
+    x = torch.zeros((B, H, W, C), dtype=torch.float64, requires_grad=True)
+    z = torch.zeros((B, H, W, 256), dtype=torch.float64)
+    y1 = co.conv_raw(x, w1.double(), 4)
+    y2 = co.conv_raw(x, w2.double(), 16)
+    y3 = co.conv_raw(torch.cat([z, x, z], dim=3), w3.double(), 1)
+    ((y1 * dz1.double()).sum() + (y2 * dz2.double()).sum() + (y3 * dz3.double()).sum()).backward()
+    wd = [ops.pack_weights(w.to(DEV), capi.BF16, want_fwd=False)[1] for w in (w1, w2, w3)]
+    out = torch.zeros((B, H, W, C), dtype=torch.bfloat16, device=DEV)
+    ops.conv_fwd([dict(x=dz1.to(DEV), w=wd[0], cin=256, kh=3, kw=5, dil=4, flip=True),
+                  dict(x=dz2.to(DEV), w=wd[1], cin=256, kh=3, kw=5, dil=16, flip=True),
+                  dict(x=dz3.to(DEV), w=wd[2], cin=128, kh=1, kw=1, dil=1, flip=True, n_off=256)], out, C)
+    assert relerr(out, x.grad) < 6e-3
+
+
 @pytest.mark.parametrize("dt", ["f32", "bf16"])
 def test_conv_dgrad_multi_segment(ops, dt):
     """d(loss)/dx of a tensor consumed by two convs (3x5 dil 2 with 128 outputs, and channels

@@ -52,3 +52,4 @@ wsum = sum(max(0, W - abs((j - 2) * dil)) for j in range(5))
 fl = 2 * B * hs * wsum * cin * cout
 print("%s dil=%d cin=%d cout=%d: %.1f us  %.1f TFLOP/s in-bounds (%.1f nominal)" %
       (mode, dil, cin, cout, ms * 1e3, fl / ms / 1e9, 2 * B * H * W * 15 * cin * cout / ms / 1e9))
+
