@@ -57,6 +57,32 @@ __device__ __forceinline__ uint4 buf_load16(__amdgpu_buffer_rsrc_t rsrc, unsigne
 }
 
 
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef unsigned u32x4s_t __attribute__((ext_vector_type(4)));
+
+// raw buffer descriptor (stride 0, 32-bit records): base, base_hi, num_records, flags
+__device__ __forceinline__ u32x4s_t make_rsrc(const void* base, unsigned bytes) {
+    const unsigned long long a = reinterpret_cast<unsigned long long>(base);
+    u32x4s_t r;
+    r.x = __builtin_amdgcn_readfirstlane((unsigned)a);
+    r.y = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32) & 0xffffu);
+    r.z = __builtin_amdgcn_readfirstlane(bytes);
+    r.w = 0x00020000u;
+    return r;
+}
+
+// `buffer_load_dwordx4 ... lds`: 64 lanes x 16 B land at LDS byte address lds_dst + 16*lane; each
+// lane's source offset is its own.  Written as inline asm so that hipcc does not put a
+// `s_waitcnt vmcnt(0)` in front of every later ds_read (it cannot tell the two LDS buffers
+// apart); the pipeline's own counted wait + barrier order the data.  M0 is saved and restored.
+__device__ __forceinline__ void glds16(u32x4s_t rsrc, unsigned lds_dst, unsigned voff) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(voff), "s"(rsrc), "s"(lds_dst)
+                 : "memory");
+}
+
 }  // namespace convk
 
 // conv_wide.hip: bf16 in / bf16 out, n_out a multiple of 256, every segment cin a multiple of 64

@@ -430,12 +430,19 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradParams p) {
 //   Per image row (64 pixels of K) one input row patch [halo + 64 + halo][128 cin] and one
 //   output-gradient row [64][128 cout] are staged; the kw taps read the SAME patch at shifted
 //   pixel rows through ds_read_b64_tr_b16, so the x operand costs 1/kw of a per-tap kernel.
-//   Rows r+1 are fetched into registers (buffer loads, zeros outside the image) while row r is
-//   multiplied, and land in the other half of a double-buffered LDS image: one barrier per row.
+//   Staging is LDS-DMA (`buffer_load_dwordx4 ... lds`, 1-KB pieces of 4 pixel rows, the swizzle
+//   applied on the source address): the pieces of row r+1 are sent off between the taps of row
+//   r's first K block and land in the other half of the LDS image; one barrier per row.
+//   MASK >= 0: bit ks*KW+t says whether K block ks of tap t overlaps the image - a compile-time
+//   pattern (all ten for W = 64 and dilation <= 8; eight for dilation 16) that leaves the row loop
+//   branch-free so the compiler can pipeline it; MASK < 0 is the general instance (uniform tests).
 constexpr int WG5_NT = 512;
 constexpr int WG5_KW = 5;      // at most 5 column taps
-constexpr int WG5_NX = 3;      // 16-byte chunks of the x row patch per lane (patch <= 96 pixels)
 constexpr int WG5_PIX = 64;    // pixels of K per stage
+constexpr int WG5_XROWS = 96;  // staged patch rows (24 pieces): 64 + 2 * pad <= 96
+// LDS map: x patch 0 at 0, x patch 1 at 32 KB, dz rows at 64 KB and 80 KB (the halves toggle by XOR)
+constexpr int WG5_XSTRIDE = 32768, WG5_D0 = 65536, WG5_DBUF = WG5_PIX * 256;
+constexpr int WG5_LDS = WG5_D0 + 2 * WG5_DBUF;
 
 struct Wgrad5Params {
     const char* x;
@@ -446,21 +453,19 @@ struct Wgrad5Params {
     int splits, mt, ntile, nwseg, pad;   // pad = halo columns staged on each side (clipped)
 };
 
+template <int KW, int MASK>
 __global__ __launch_bounds__(WG5_NT, 2) void wgrad5_kernel(Wgrad5Params p) {
     constexpr int ES = 2;
     constexpr int ROWB = 256;       // bytes per staged pixel row: 128 channels
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int pwx = WG5_PIX + 2 * p.pad;                    // staged pixel rows of the x patch
-    const int xbuf_bytes = pwx * ROWB, dbuf_bytes = WG5_PIX * ROWB;
-    char* Xs = smem;                                        // 2 x [pwx][128 ci]
-    char* Ds = smem + 2 * xbuf_bytes;                       // 2 x [64][128 co]
+    const int pwx = WG5_PIX + 2 * p.pad;                    // patch rows that hold data
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
     const int li = lane & 15, lg = lane >> 4;
-    const int H = p.H, W = p.W, kw = p.kw, dil = p.dil, pad = p.pad;
+    const int H = p.H, W = p.W, dil = p.dil, pad = p.pad;
 
     int bid = blockIdx.x;
     const int nt = bid % p.ntile; bid /= p.ntile;
@@ -474,9 +479,9 @@ __global__ __launch_bounds__(WG5_NT, 2) void wgrad5_kernel(Wgrad5Params p) {
     const int unit_begin = blockIdx.y * per;
     const int unit_end = min(units_total, unit_begin + per);
 
-    float4_t acc[WG5_KW][2][4];
+    float4_t acc[KW][2][4];
 #pragma unroll
-    for (int t = 0; t < WG5_KW; ++t)
+    for (int t = 0; t < KW; ++t)
 #pragma unroll
         for (int m = 0; m < 2; ++m)
 #pragma unroll
@@ -484,18 +489,31 @@ __global__ __launch_bounds__(WG5_NT, 2) void wgrad5_kernel(Wgrad5Params p) {
 
     const long long xbytes = ((long long)(p.B * H * W - 1) * p.ld_x + p.cin) * ES;
     const long long dbytes = ((long long)(p.B * H * W - 1) * p.ld_dz + p.cout) * ES;
-    const __amdgpu_buffer_rsrc_t rsrc_x = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (int)xbytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsrc_d = __builtin_amdgcn_make_buffer_rsrc((void*)p.dz, 0, (int)dbytes, 0x00020000);
+    const u32x4s_t rsrc_x = make_rsrc(p.x, (unsigned)xbytes);
+    const u32x4s_t rsrc_d = make_rsrc(p.dz, (unsigned)dbytes);
+    const unsigned lds0 = (unsigned)(uintptr_t)((lds_void_t*)smem);
 
-    // staging plan: lane -> (pixel row r0 + 32u, 16-byte chunk c of 8 channels); 512 lanes cover
-    // 32 pixel rows x 16 chunks per pass, and the swizzle ignores bit 5 of the row, so one LDS
-    // offset serves every pass
-    const int sc = tid & 15, r0 = tid >> 4;
-    const int st_lds = r0 * ROWB + (((sc >> 1) ^ tr_func(r0)) * 32) + (sc & 1) * 16;
-    const int x_ch = (m0 + sc * 8 < p.cin) ? (m0 + sc * 8) : -1;
-    const int d_ch = (n0 + sc * 8 < p.cout) ? (n0 + sc * 8) : -1;
-
-    uint4 regX[WG5_NX], regD[2];
+    // staging plan: wave w moves x-patch pieces w, w+8, w+16 and dz pieces w, w+8 (1 KB = 4 pixel
+    // rows x 256 B).  Lane l of a piece is (row = l >> 4, 16-byte slot s = l & 15) and fetches
+    // channel chunk ((s >> 1) ^ tr_func(row)) * 2 + (s & 1): the swizzle the transposed reads
+    // below expect, applied on the SOURCE address.  Rows past the patch get zeros.
+    const int prow = lane >> 4, pslot = lane & 15;
+    int x_r[3], x_off[3], d_r[2], d_off[2];
+    bool x_ok[3], d_ok[2];
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {
+        x_r[u] = (wave + 8 * u) * 4 + prow;
+        const int chn = m0 + ((((pslot >> 1) ^ tr_func(x_r[u])) << 1) | (pslot & 1)) * 8;
+        x_ok[u] = x_r[u] < pwx && chn < p.cin;
+        x_off[u] = ((x_r[u] - pad) * p.ld_x + chn) * ES;
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        d_r[u] = (wave + 8 * u) * 4 + prow;
+        const int chn = n0 + ((((pslot >> 1) ^ tr_func(d_r[u])) << 1) | (pslot & 1)) * 8;
+        d_ok[u] = chn < p.cout;
+        d_off[u] = (d_r[u] * p.ld_dz + chn) * ES;
+    }
     // unit -> (b, h, ws); returns false when the shifted input row is outside the image
     auto decode = [&](int unit, int& b, int& h, int& ws) {
         const int seg = unit % p.nwseg;
@@ -506,28 +524,18 @@ __global__ __launch_bounds__(WG5_NT, 2) void wgrad5_kernel(Wgrad5Params p) {
         const int hh = h + sy;
         return hh >= 0 && hh < H;
     };
-    auto load_unit = [&](int b, int h, int ws) {
-        const int hh = h + sy;
-#pragma unroll
-        for (int u = 0; u < WG5_NX; ++u) {
-            const int pr = r0 + 32 * u;
-            const int w = ws - pad + pr;
-            const bool ok = pr < pwx && x_ch >= 0 && w >= 0 && w < W;
-            regX[u] = buf_load16(rsrc_x, ok ? (unsigned)((((b * H + hh) * W + w) * p.ld_x + x_ch) * ES) : BUF_OOB);
+    auto issue_piece = [&](int k, int b, int h, int ws, int bsel, bool live) {    // k = 0..4, compile-time at every call
+        if (k < 3) {
+            const int w = ws - pad + x_r[k];
+            const bool ok = live && x_ok[k] && w >= 0 && w < W;
+            glds16(rsrc_x, lds0 + bsel * WG5_XSTRIDE + (wave + 8 * k) * 1024,
+                   ok ? (unsigned)(((b * H + h + sy) * W + ws) * p.ld_x * ES + x_off[k]) : BUF_OOB);
+        } else {
+            const int u = k - 3;
+            const bool ok = live && d_ok[u] && ws + d_r[u] < W;
+            glds16(rsrc_d, lds0 + WG5_D0 + bsel * WG5_DBUF + (wave + 8 * u) * 1024,
+                   ok ? (unsigned)(((b * H + h) * W + ws) * p.ld_dz * ES + d_off[u]) : BUF_OOB);
         }
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const int w = ws + r0 + 32 * u;
-            const bool ok = d_ch >= 0 && w < W;
-            regD[u] = buf_load16(rsrc_d, ok ? (unsigned)((((b * H + h) * W + w) * p.ld_dz + d_ch) * ES) : BUF_OOB);
-        }
-    };
-    auto store_unit = [&](int bsel) {
-#pragma unroll
-        for (int u = 0; u < WG5_NX; ++u)
-            if (r0 + 32 * u < pwx) *reinterpret_cast<uint4*>(Xs + bsel * xbuf_bytes + st_lds + u * 32 * ROWB) = regX[u];
-#pragma unroll
-        for (int u = 0; u < 2; ++u) *reinterpret_cast<uint4*>(Ds + bsel * dbuf_bytes + st_lds + u * 32 * ROWB) = regD[u];
     };
     // next unit at or after `u` whose input row is inside the image
     auto seek = [&](int u, int& b, int& h, int& ws) {
@@ -535,53 +543,68 @@ __global__ __launch_bounds__(WG5_NT, 2) void wgrad5_kernel(Wgrad5Params p) {
         return u;
     };
 
+    // transposed-read addresses (LDS bytes) for buffer 0 / K block 0 / first 16-channel block of the
+    // wave; the other blocks are an XOR of the chunk field (blk ^ f = (blk0 ^ f) ^ i for i below
+    // blk0's alignment), K block 1 is + 32 rows (tr_func ignores bit 5) and the two halves are +- a fixed stride
+    const int q = li >> 2, pp = li & 3;
+    const int r1 = lg * 8 + q;
+    unsigned da = lds0 + WG5_D0 + r1 * ROWB + (((wn * 4) ^ tr_func(r1)) * 32) + pp * 8;   // hi row = + 4 rows
+    unsigned xa[KW][2];
+#pragma unroll
+    for (int t = 0; t < KW; ++t) {
+        const int x1 = pad + (t - KW / 2) * dil + r1, x2 = x1 + 4;
+        xa[t][0] = lds0 + x1 * ROWB + (((wm * 2) ^ tr_func(x1)) * 32) + pp * 8;
+        xa[t][1] = lds0 + x2 * ROWB + (((wm * 2) ^ tr_func(x2)) * 32) + pp * 8;
+    }
+    auto tr2 = [&](unsigned lo, unsigned hi) {
+        const short4_t a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4_t*)(uintptr_t)(lo));
+        const short4_t b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4_t*)(uintptr_t)(hi));
+        return short8_t{a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+    };
+
     int cb, ch, cws;
     int cur = seek(unit_begin, cb, ch, cws);
     int buf = 0;
     if (cur < unit_end) {
-        load_unit(cb, ch, cws);
-        store_unit(0);
+#pragma unroll
+        for (int k = 0; k < 5; ++k) issue_piece(k, cb, ch, cws, 0, true);
     }
-    __syncthreads();
-    const int q = li >> 2, pp = li & 3;
     while (cur < unit_end) {
         int nb, nh, nws;
         const int nxt = seek(cur + 1, nb, nh, nws);
-        if (nxt < unit_end) load_unit(nb, nh, nws);          // in flight while this row is multiplied
-        const char* Xc = Xs + buf * xbuf_bytes;
-        const char* Dc = Ds + buf * dbuf_bytes;
-#pragma unroll 1
+        const bool more = nxt < unit_end;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // my pieces of this row have landed ...
+        __builtin_amdgcn_s_barrier();                        // ... everybody's have, and the other half is free
+        // one image row: 2 K blocks of 32 pixels x KW taps x (2 x 4) MFMAs; the pieces of the next
+        // row are sent on their way between the taps of the first K block (zeros when there is none)
+#pragma unroll
         for (int ks = 0; ks < WG5_PIX / 32; ++ks) {
             const int px0 = cws + ks * 32;                   // first output pixel of this K block
-            if (px0 >= W) continue;
-            const int r1 = ks * 32 + lg * 8 + q, r2 = r1 + 4;
+            if (MASK < 0 && px0 >= W) {
+                if (ks == 0) {
+#pragma unroll
+                    for (int k = 0; k < 5; ++k) issue_piece(k, nb, nh, nws, buf ^ 1, more);
+                }
+                continue;
+            }
             short8_t bf[4];
 #pragma unroll
-            for (int n = 0; n < 4; ++n) {
-                const int blk = wn * 4 + n;
-                const short4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                    (__attribute__((address_space(3))) short4_t*)(Dc + r1 * ROWB + ((blk ^ tr_func(r1)) * 32) + pp * 8));
-                const short4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                    (__attribute__((address_space(3))) short4_t*)(Dc + r2 * ROWB + ((blk ^ tr_func(r2)) * 32) + pp * 8));
-                bf[n] = short8_t{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-            }
+            for (int n = 0; n < 4; ++n) bf[n] = tr2((da ^ (n * 32)) + ks * 32 * ROWB, (da ^ (n * 32)) + ks * 32 * ROWB + 4 * ROWB);
 #pragma unroll
-            for (int t = 0; t < WG5_KW; ++t) {
-                if (t >= kw) break;
-                const int sx = (t - kw / 2) * dil;
+            for (int t = 0; t < KW; ++t) {
+                if (ks == 0) {
+#pragma unroll
+                    for (int k = 0; k < 5; ++k)
+                        if (k * KW / 5 == t) issue_piece(k, nb, nh, nws, buf ^ 1, more);
+                }
+                const int sx = (t - KW / 2) * dil;
                 // input pixels px0+sx .. px0+sx+31 all outside the image: nothing to add (uniform)
-                if (px0 + sx + 31 < 0 || px0 + sx >= W) continue;
-                const int x1 = pad + sx + r1, x2 = x1 + 4;   // patch pixel rows
+                if (MASK >= 0 && !((MASK >> (ks * KW + t)) & 1)) continue;     // compile-time pattern
+                if (MASK < 0 && (px0 + sx + 31 < 0 || px0 + sx >= W)) continue;
                 short8_t af[2];
 #pragma unroll
-                for (int m = 0; m < 2; ++m) {
-                    const int blk = wm * 2 + m;
-                    const short4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                        (__attribute__((address_space(3))) short4_t*)(Xc + x1 * ROWB + ((blk ^ tr_func(x1)) * 32) + pp * 8));
-                    const short4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                        (__attribute__((address_space(3))) short4_t*)(Xc + x2 * ROWB + ((blk ^ tr_func(x2)) * 32) + pp * 8));
-                    af[m] = short8_t{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-                }
+                for (int m = 0; m < 2; ++m)
+                    af[m] = tr2((xa[t][0] ^ (m * 32)) + ks * 32 * ROWB, (xa[t][1] ^ (m * 32)) + ks * 32 * ROWB);
 #pragma unroll
                 for (int m = 0; m < 2; ++m)
 #pragma unroll
@@ -589,16 +612,19 @@ __global__ __launch_bounds__(WG5_NT, 2) void wgrad5_kernel(Wgrad5Params p) {
                         acc[t][m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[m], bf[n], acc[t][m][n], 0, 0, 0);
             }
         }
-        if (nxt < unit_end) store_unit(buf ^ 1);             // that half was last read one barrier ago
-        __syncthreads();
+        // switch halves by +- the stride (not XOR: a dead tap's base row may be negative)
+        const int dxa = buf ? -WG5_XSTRIDE : WG5_XSTRIDE, dda = buf ? -WG5_DBUF : WG5_DBUF;
         buf ^= 1;
+        da += dda;
+#pragma unroll
+        for (int t = 0; t < KW; ++t) { xa[t][0] += dxa; xa[t][1] += dxa; }
         cur = nxt; cb = nb; ch = nh; cws = nws;
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the last row's (all-zero) prefetch
 
 #pragma unroll
-    for (int t = 0; t < WG5_KW; ++t) {
-        if (t >= kw) break;
-        float* slab = p.slabs + ((long long)blockIdx.y * p.kh * kw + (ti * kw + t)) * p.cin * p.cout;
+    for (int t = 0; t < KW; ++t) {
+        float* slab = p.slabs + ((long long)blockIdx.y * p.kh * KW + (ti * KW + t)) * p.cin * p.cout;
 #pragma unroll
         for (int m = 0; m < 2; ++m)
 #pragma unroll
@@ -783,10 +809,30 @@ extern "C" int cutie_conv_wgrad(const void* x, int ld_x, int cin, const void* dz
         }
         q.pad = pad;
         const int pwx = WG5_PIX + 2 * pad;
-        if (pwx * 16 <= WG5_NX * WG5_NT) {
-            const size_t lds5 = (size_t)2 * (pwx + WG5_PIX) * 256;
-            CUTIE_CHECK_HIP(hipFuncSetAttribute((const void*)wgrad5_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds5));
-            hipLaunchKernelGGL(wgrad5_kernel, dim3(kh * q.mt * q.ntile, q.splits), dim3(WG5_NT), lds5, stream, q);
+        if (pwx <= WG5_XROWS && (kw == 1 || kw == 3 || kw == 5)) {
+            // liveness pattern of the (K block, tap) pairs when a row is one 64-pixel segment
+            int mask = -1;
+            if (q.nwseg == 1 && kw == 5 && W > 32) {
+                mask = 0;
+                for (int ks = 0; ks < 2; ++ks)
+                    for (int t = 0; t < kw; ++t) {
+                        const int px0 = ks * 32, sx = (t - kw / 2) * dil;
+                        if (!(px0 + sx + 31 < 0 || px0 + sx >= W)) mask |= 1 << (ks * kw + t);
+                    }
+            }
+            const dim3 grid5(kh * q.mt * q.ntile, q.splits);
+#define CUTIE_WG5_LAUNCH(KW_, MASK_)                                                                              \
+    do {                                                                                                          \
+        CUTIE_CHECK_HIP(hipFuncSetAttribute((const void*)wgrad5_kernel<KW_, MASK_>,                               \
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, WG5_LDS));                \
+        hipLaunchKernelGGL((wgrad5_kernel<KW_, MASK_>), grid5, dim3(WG5_NT), WG5_LDS, stream, q);                 \
+    } while (0)
+            if (kw == 5 && mask == 0x3FF) CUTIE_WG5_LAUNCH(5, 0x3FF);
+            else if (kw == 5 && mask == 0x1FE) CUTIE_WG5_LAUNCH(5, 0x1FE);
+            else if (kw == 5) CUTIE_WG5_LAUNCH(5, -1);
+            else if (kw == 3) CUTIE_WG5_LAUNCH(3, -1);
+            else CUTIE_WG5_LAUNCH(1, -1);
+#undef CUTIE_WG5_LAUNCH
             CUTIE_CHECK_LAUNCH();
             hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)g_red), dim3(256), 0, stream, (const float*)workspace,
                                q.splits, n_w, dw, accumulate);

@@ -26,32 +26,6 @@ constexpr int CW_NT = 512;
 constexpr int CW_A0 = 0, CW_B0 = 65536, CW_BUF = 32768;    // LDS map: A0 A1 B0 B1, 32 KB each
 constexpr int CW_LDS = 131072;
 
-typedef __attribute__((address_space(3))) void lds_void_t;
-typedef unsigned u32x4s_t __attribute__((ext_vector_type(4)));
-
-// raw buffer descriptor (stride 0, 32-bit records): base, base_hi, num_records, flags
-__device__ __forceinline__ u32x4s_t make_rsrc(const void* base, unsigned bytes) {
-    const unsigned long long a = reinterpret_cast<unsigned long long>(base);
-    u32x4s_t r;
-    r.x = __builtin_amdgcn_readfirstlane((unsigned)a);
-    r.y = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32) & 0xffffu);
-    r.z = __builtin_amdgcn_readfirstlane(bytes);
-    r.w = 0x00020000u;
-    return r;
-}
-
-// `buffer_load_dwordx4 ... lds`: 64 lanes x 16 B land at LDS byte address lds_dst + 16*lane; each
-// lane's source offset is its own.  Written as inline asm so that hipcc does not put a
-// `s_waitcnt vmcnt(0)` in front of every later ds_read (it cannot tell the two LDS buffers
-// apart); the pipeline's own counted wait + barrier order the data.  M0 is saved and restored.
-__device__ __forceinline__ void glds16(u32x4s_t rsrc, unsigned lds_dst, unsigned voff) {
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep)
-                 : "v"(voff), "s"(rsrc), "s"(lds_dst)
-                 : "memory");
-}
-
 __global__ __launch_bounds__(CW_NT) void conv_wide_kernel(ConvParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;

@@ -310,6 +310,8 @@ WGRAD_CASES = [
     (3, 6, 40, 64, 18, 1, 1, 1),
     (1, 9, 80, 96, 72, 3, 5, 2),
     (1, 5, 130, 64, 64, 3, 3, 4),
+    (8, 64, 64, 128, 128, 3, 5, 16),    # many rows per workgroup: both LDS halves, dead (K block, tap) pairs
+    (8, 64, 64, 128, 128, 3, 5, 8),
 ]
 
 
