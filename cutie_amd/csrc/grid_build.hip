@@ -30,6 +30,7 @@ struct GridArgs {
     double* key_h;   // workspace [T]
     int32_t* key_row;  // workspace [T]
     int32_t* key_col;  // workspace [T]
+    int cap;           // tokens per document whose scratch fits in LDS
 };
 
 __device__ __forceinline__ bool key_less(int rj, double vj, double hj, int dj, int j,
@@ -41,20 +42,33 @@ __device__ __forceinline__ bool key_less(int rj, double vj, double hj, int dj, i
     return j < i;
 }
 
-__global__ __launch_bounds__(256) void grid_build_kernel(GridArgs a) {
+constexpr int GB_NT = 1024;
+
+__global__ __launch_bounds__(GB_NT) void grid_build_kernel(GridArgs a) {
     extern __shared__ __attribute__((aligned(16))) int32_t lds[];
     const int rows = a.rows, cols = a.cols;
     int32_t* g = lds;                       // [rows*cols]
     int32_t* row_start = lds + rows * cols; // [rows]
-    int32_t* flag = row_start + rows;       // [1]
+    int32_t* flag = row_start + rows;       // [1] (+ pad to 8 bytes)
 
     const int doc = blockIdx.x;
     const int t0 = a.doc_off[doc];
     const int n = a.doc_off[doc + 1] - t0;
     const int tid = threadIdx.x;
 
-    for (int i = tid; i < rows * cols; i += blockDim.x) g[i] = 0;
-    for (int i = tid; i < rows; i += blockDim.x) row_start[i] = -1;
+    // per-token scratch (keys, ids, sorted order): in LDS when the document fits the reserved
+    // capacity (every lane re-reads all keys in the rank loop), else in the caller's workspace
+    const bool in_lds = n <= a.cap;
+    char* kbase = reinterpret_cast<char*>(lds) + (((size_t)(rows * cols + rows + 2) * 4 + 7) & ~(size_t)7);
+    double* key_v = in_lds ? reinterpret_cast<double*>(kbase) : a.key_v + t0;
+    double* key_h = in_lds ? key_v + a.cap : a.key_h + t0;
+    int32_t* key_row = in_lds ? reinterpret_cast<int32_t*>(key_h + a.cap) : a.key_row + t0;
+    int32_t* key_col = in_lds ? key_row + a.cap : a.key_col + t0;
+    int32_t* key_id = in_lds ? key_col + a.cap : const_cast<int32_t*>(a.tok_id) + t0;
+    int32_t* order = in_lds ? key_id + a.cap : a.tok_order + t0;
+
+    for (int i = tid; i < rows * cols; i += GB_NT) g[i] = 0;
+    for (int i = tid; i < rows; i += GB_NT) row_start[i] = -1;
     if (tid == 0) *flag = 0;
     __syncthreads();
 
@@ -62,9 +76,9 @@ __global__ __launch_bounds__(256) void grid_build_kernel(GridArgs a) {
     const int right = a.doc_extent[doc * 4 + 2], bottom = a.doc_extent[doc * 4 + 3];
 
     // ---- keys (:499-504)
-    for (int i = tid; i < n; i += blockDim.x) {
-        const int x_left = a.tok_box[(t0 + i) * 4 + 0], y_top = a.tok_box[(t0 + i) * 4 + 1];
-        const int x_right = a.tok_box[(t0 + i) * 4 + 2], y_bottom = a.tok_box[(t0 + i) * 4 + 3];
+    for (int i = tid; i < n; i += GB_NT) {
+        const int4 box = *reinterpret_cast<const int4*>(a.tok_box + (size_t)(t0 + i) * 4);
+        const int x_left = box.x, y_top = box.y, x_right = box.z, y_bottom = box.w;
         bool bad = (bottom == top) || (right == left);
         double v_c = 0.0, h_c = 0.0;
         int row = 0, col = 0;
@@ -80,50 +94,51 @@ __global__ __launch_bounds__(256) void grid_build_kernel(GridArgs a) {
             }
         }
         if (bad) atomicOr(flag, 1);
-        a.key_v[t0 + i] = v_c;
-        a.key_h[t0 + i] = h_c;
-        a.key_row[t0 + i] = row;
-        a.key_col[t0 + i] = col;
+        key_v[i] = v_c;
+        key_h[i] = h_c;
+        key_row[i] = row;
+        key_col[i] = col;
+        if (in_lds) key_id[i] = a.tok_id[t0 + i];
     }
     __syncthreads();  // workgroup-scope fence: the keys are re-read below by other lanes
     if (*flag) {
         if (tid == 0) a.status[doc] = 1;
-        for (int i = tid; i < rows * cols; i += blockDim.x) a.grid[(size_t)doc * rows * cols + i] = 0;
+        for (int i = tid; i < rows * cols; i += GB_NT) a.grid[(size_t)doc * rows * cols + i] = 0;
         return;
     }
 
-    // ---- stable sort (:507) as a rank by counting; all lanes read key j together
-    for (int i = tid; i < n; i += blockDim.x) {
-        const int ri = a.key_row[t0 + i];
-        const double vi = a.key_v[t0 + i], hi = a.key_h[t0 + i];
-        const int di = a.tok_id[t0 + i];
+    // ---- stable sort (:507) as a rank by counting; all lanes read key j together (broadcast)
+    for (int i = tid; i < n; i += GB_NT) {
+        const int ri = key_row[i];
+        const double vi = key_v[i], hi = key_h[i];
+        const int di = key_id[i];
         int rank = 0;
+#pragma unroll 4
         for (int j = 0; j < n; ++j) {
-            rank += key_less(a.key_row[t0 + j], a.key_v[t0 + j], a.key_h[t0 + j], a.tok_id[t0 + j], j,
-                             ri, vi, hi, di, i) ? 1 : 0;
+            rank += key_less(key_row[j], key_v[j], key_h[j], key_id[j], j, ri, vi, hi, di, i) ? 1 : 0;
         }
-        a.tok_order[t0 + rank] = i;
+        order[rank] = i;
     }
     __syncthreads();
 
     // ---- first sorted position of every row
-    for (int p = tid; p < n; p += blockDim.x) {
-        const int r = a.key_row[t0 + a.tok_order[t0 + p]];
-        if (p == 0 || a.key_row[t0 + a.tok_order[t0 + p - 1]] != r) row_start[r] = p;
+    for (int p = tid; p < n; p += GB_NT) {
+        const int r = key_row[order[p]];
+        if (p == 0 || key_row[order[p - 1]] != r) row_start[r] = p;
     }
     __syncthreads();
 
     // ---- one lane per row replays the sequential placement (:508-557)
     const size_t cell0 = (size_t)doc * rows * cols;
-    for (int r = tid; r < rows; r += blockDim.x) {
+    for (int r = tid; r < rows; r += GB_NT) {
         int p = row_start[r];
         if (p < 0) continue;
         int32_t* gr = g + r * cols;
         for (; p < n; ++p) {
-            const int i = a.tok_order[t0 + p];
-            if (a.key_row[t0 + i] != r) break;
-            int col = a.key_col[t0 + i];
-            const int dict_id = a.tok_id[t0 + i];
+            const int i = order[p];
+            if (key_row[i] != r) break;
+            int col = key_col[i];
+            const int dict_id = key_id[i];
             while (col < cols && gr[col] != 0) ++col;
             bool write = true;
             if (a.strategy == 0) {
@@ -157,7 +172,10 @@ __global__ __launch_bounds__(256) void grid_build_kernel(GridArgs a) {
         }
     }
     __syncthreads();
-    for (int i = tid; i < rows * cols; i += blockDim.x) a.grid[cell0 + i] = g[i];
+    for (int i = tid; i < rows * cols; i += GB_NT) a.grid[cell0 + i] = g[i];
+    if (in_lds) {
+        for (int i = tid; i < n; i += GB_NT) a.tok_order[t0 + i] = order[i];
+    }
     if (tid == 0) a.status[doc] = 0;
 }
 
@@ -179,13 +197,14 @@ extern "C" int cutie_grid_build(const int32_t* tok_box, const int32_t* tok_id, c
     CUTIE_CHECK_ARG(rows >= 1 && cols >= 1 && rows <= 1024, "grid_build: rows=%d cols=%d out of range", rows, cols);
     CUTIE_CHECK_ARG(strategy == 0 || strategy == 1,
                     "grid_build: positional_mapping_strategy %d is not built (0 and 1 are)", strategy);
-    const size_t lds_bytes = ((size_t)rows * cols + rows + 4) * sizeof(int32_t);
+    const size_t lds_bytes = ((size_t)rows * cols + rows + 2) * sizeof(int32_t);
     CUTIE_CHECK_ARG(lds_bytes <= 160 * 1024, "grid_build: %dx%d grid needs %zu B of LDS (max 163840)", rows,
                     cols, lds_bytes);
     if (n_docs == 0) return CUTIE_OK;
     CUTIE_CHECK_ARG(grid && labels && ps_x && ps_y && tok_order && tok_place && status && doc_off && doc_extent,
                     "grid_build: null pointer");
     CUTIE_CHECK_ARG(n_tokens == 0 || (tok_box && tok_id && tok_ecid), "grid_build: null token arrays");
+    CUTIE_CHECK_ARG(cutie::aligned16(tok_box), "grid_build: tok_box must be 16-byte aligned");
     if (workspace_bytes < cutie_grid_build_workspace_bytes(n_tokens) || !workspace) {
         cutie::set_error("grid_build: workspace %zu < %zu", workspace_bytes,
                          cutie_grid_build_workspace_bytes(n_tokens));
@@ -209,11 +228,15 @@ extern "C" int cutie_grid_build(const int32_t* tok_box, const int32_t* tok_id, c
     a.key_row = (int32_t*)(a.key_h + t);
     a.key_col = a.key_row + t;
 
-    if (lds_bytes > 64 * 1024) {
-        CUTIE_CHECK_HIP(hipFuncSetAttribute((const void*)grid_build_kernel,
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-    }
-    hipLaunchKernelGGL(grid_build_kernel, dim3(n_docs), dim3(256), lds_bytes, stream, a);
+    // per-token scratch in LDS: 32 bytes a token, up to 2048 tokens a document or what is left
+    const size_t grid_part = (lds_bytes + 7) & ~(size_t)7;
+    size_t cap = (160 * 1024 - grid_part) / 32;
+    if (cap > 2048) cap = 2048;
+    a.cap = (int)cap;
+    const size_t lds_total = grid_part + cap * 32;
+    CUTIE_CHECK_HIP(hipFuncSetAttribute((const void*)grid_build_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        (int)lds_total));
+    hipLaunchKernelGGL(grid_build_kernel, dim3(n_docs), dim3(GB_NT), lds_total, stream, a);
     CUTIE_CHECK_LAUNCH();
     return CUTIE_OK;
 }

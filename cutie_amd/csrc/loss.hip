@@ -82,94 +82,233 @@ __device__ __forceinline__ unsigned sortable(float f) {
     return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
 }
 
-constexpr int HNM_T = 1024;
+// ---------------------------------------------------------------------------------------------
+// Hard negative mining (model_cutie.py:116-130) over many workgroups.
+//   num_bg = min(#background, ratio * #foreground); the selected background cells are the num_bg
+//   with the largest ce, ties broken toward the lower index (tf.nn.top_k).  The num_bg-th largest
+//   key is found by a three-level radix select (11 + 11 + 10 bits of the order-preserving integer
+//   image of the float) - one histogram kernel per level, every workgroup redoing the small bin
+//   scan of the previous level - then the cells equal to the threshold are counted per 1024-cell
+//   chunk so that the final kernel can take the first k_eq of them in index order.
+//   All sums are fixed-order (per-chunk partials, then one thread): the loss is deterministic.
+constexpr int HNM_T = 256;
+constexpr int HNM_CHUNK = 1024;       // cells per workgroup (4 per lane)
+constexpr int HNM_B0 = 2048, HNM_B1 = 2048, HNM_B2 = 1024;
 
-__device__ __forceinline__ float block_sum_f(float v, float* sh) {
-    v = wave_sum(v);
-    __syncthreads();
-    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
-    __syncthreads();
-    float t = 0.f;
-    for (int w = 0; w < HNM_T / 64; ++w) t += sh[w];
-    return t;
+struct HnmWs {
+    int* counts;     // [0] nfg [1] nbg [2..7] sel: b0, k1, b1, k2, (unused)
+    int* hist0;      // [2048]
+    int* hist1;      // [2048]
+    int* hist2;      // [1024]
+    int* tie_cnt;    // [chunks]
+    float* sum_fg;   // [chunks]
+    float* sum_sel;  // [chunks]
+};
+constexpr int HNM_INT_HEAD = 8 + HNM_B0 + HNM_B1 + HNM_B2;
+
+__device__ __forceinline__ HnmWs hnm_ws(void* ws, int chunks) {
+    HnmWs w;
+    w.counts = reinterpret_cast<int*>(ws);
+    w.hist0 = w.counts + 8;
+    w.hist1 = w.hist0 + HNM_B0;
+    w.hist2 = w.hist1 + HNM_B1;
+    w.tie_cnt = w.hist2 + HNM_B2;
+    w.sum_fg = reinterpret_cast<float*>(w.tie_cnt + chunks);
+    w.sum_sel = w.sum_fg + chunks;
+    return w;
 }
-__device__ __forceinline__ int block_sum_i(int v, int* sh) {
+
+__device__ __forceinline__ int block_sum_i256(int v, int* sh) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     __syncthreads();
     if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
     __syncthreads();
-    int t = 0;
-    for (int w = 0; w < HNM_T / 64; ++w) t += sh[w];
-    return t;
+    return sh[0] + sh[1] + sh[2] + sh[3];
+}
+__device__ __forceinline__ float block_sum_f256(float v, float* sh) {
+    v = wave_sum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return ((sh[0] + sh[1]) + sh[2]) + sh[3];
 }
 
-// Single workgroup: counts, radix select of the num_bg-th largest background ce (4 x 8 bit),
-// then an index-ordered pass that breaks ties toward the lower index (tf.nn.top_k).
-__global__ __launch_bounds__(HNM_T) void hnm_kernel(const float* __restrict__ ce, const int32_t* __restrict__ labels,
-                                                    int64_t n_cells, int ratio, float* __restrict__ weight,
-                                                    float* __restrict__ loss_out) {
-    __shared__ int hist[256];
-    __shared__ float shf[HNM_T / 64];
-    __shared__ int shi[HNM_T / 64];
-    __shared__ unsigned s_prefix;
-    __shared__ long long s_k;
-    __shared__ int s_base;
-    const int tid = threadIdx.x;
+__device__ __forceinline__ long long hnm_num_bg(const int* counts, int ratio, bool& all_bg) {
+    const long long nfg = counts[0], nbg = counts[1];
+    const long long want = (long long)ratio * nfg;
+    const long long num_bg = want < nbg ? want : nbg;     // model_cutie.py:124-125
+    all_bg = num_bg == nbg;
+    return num_bg;
+}
 
+// Which bin holds the k-th largest key (k >= 1), and how many of that bin's keys are wanted.
+// All 256 lanes take part; hist has `bins` (a multiple of 256) entries.  sh: 260 ints.
+__device__ __forceinline__ void hnm_select(const int* __restrict__ hist, int bins, long long k, int* sh, int& bin,
+                                           long long& k_in) {
+    const int per = bins / HNM_T;
+    const int tid = threadIdx.x;
+    int mine = 0;
+    for (int i = 0; i < per; ++i) mine += hist[tid * per + i];
+    __syncthreads();
+    sh[tid] = mine;
+    __syncthreads();
+    if (tid == 0) {
+        // walk the lane sums from the top bin down, then the bins of the lane that holds rank k
+        long long rem = k;
+        int t = HNM_T - 1;
+        for (; t > 0; --t) {
+            if (rem <= sh[t]) break;
+            rem -= sh[t];
+        }
+        int bsel = t * per + per - 1;
+        for (; bsel > t * per; --bsel) {
+            const int h = hist[bsel];
+            if (rem <= h) break;
+            rem -= h;
+        }
+        sh[256] = bsel;
+        sh[257] = (int)rem;
+    }
+    __syncthreads();
+    bin = sh[256];
+    k_in = sh[257];
+    __syncthreads();
+}
+
+// level 0: counts, foreground ce partial sums, histogram of the top 11 key bits of background cells
+__global__ __launch_bounds__(HNM_T) void hnm_count_kernel(const float* __restrict__ ce, const int32_t* __restrict__ labels,
+                                                          int64_t n_cells, int chunks, void* ws_) {
+    __shared__ int hist[HNM_B0];
+    __shared__ int shi[4];
+    __shared__ float shf[4];
+    const HnmWs ws = hnm_ws(ws_, chunks);
+    const int tid = threadIdx.x;
+    for (int i = tid; i < HNM_B0; i += HNM_T) hist[i] = 0;
+    __syncthreads();
     int nfg = 0, nbg = 0;
     float sum_fg = 0.f;
-    for (int64_t i = tid; i < n_cells; i += HNM_T) {
-        if (labels[i] != 0) { ++nfg; sum_fg += ce[i]; } else { ++nbg; }
-    }
-    nfg = block_sum_i(nfg, shi);
-    nbg = block_sum_i(nbg, shi);
-    sum_fg = block_sum_f(sum_fg, shf);
-    const long long want = (long long)ratio * (long long)nfg;
-    const long long num_bg = want < (long long)nbg ? want : (long long)nbg;  // model_cutie.py:124-125
-
-    unsigned thr = 0;           // sortable key of the num_bg-th largest background ce
-    long long k_eq = 0;         // how many cells equal to thr are selected
-    const bool all_bg = (num_bg == (long long)nbg);
-    if (!all_bg && num_bg > 0) {
-        if (tid == 0) { s_prefix = 0; s_k = num_bg; }
-        __syncthreads();
-        for (int pass = 0; pass < 4; ++pass) {
-            const int shift = 24 - 8 * pass;
-            for (int i = tid; i < 256; i += HNM_T) hist[i] = 0;
-            __syncthreads();
-            const unsigned prefix = s_prefix;
-            const unsigned mask = pass == 0 ? 0u : (0xffffffffu << (shift + 8));
-            for (int64_t i = tid; i < n_cells; i += HNM_T) {
-                if (labels[i] == 0) {
-                    const unsigned u = sortable(ce[i]);
-                    if ((u & mask) == prefix) atomicAdd(&hist[(u >> shift) & 255], 1);
-                }
-            }
-            __syncthreads();
-            if (tid == 0) {
-                long long k = s_k;
-                int b = 255;
-                for (; b > 0; --b) {
-                    if (k <= hist[b]) break;
-                    k -= hist[b];
-                }
-                s_k = k;
-                s_prefix = prefix | ((unsigned)b << shift);
-            }
-            __syncthreads();
+    const int64_t base = (int64_t)blockIdx.x * HNM_CHUNK;
+#pragma unroll
+    for (int u = 0; u < HNM_CHUNK / HNM_T; ++u) {
+        const int64_t i = base + u * HNM_T + tid;
+        if (i < n_cells) {
+            const float c = ce[i];
+            if (labels[i] != 0) { ++nfg; sum_fg += c; }
+            else { ++nbg; atomicAdd(&hist[sortable(c) >> 21], 1); }
         }
-        thr = s_prefix;
-        k_eq = s_k;
     }
+    nfg = block_sum_i256(nfg, shi);
+    nbg = block_sum_i256(nbg, shi);
+    sum_fg = block_sum_f256(sum_fg, shf);
+    if (tid == 0) {
+        if (nfg) atomicAdd(&ws.counts[0], nfg);
+        if (nbg) atomicAdd(&ws.counts[1], nbg);
+        ws.sum_fg[blockIdx.x] = sum_fg;
+    }
+    for (int i = tid; i < HNM_B0; i += HNM_T)
+        if (hist[i]) atomicAdd(&ws.hist0[i], hist[i]);
+}
 
-    const float w_fg = 1.f / (float)nfg;          // inf when nfg == 0; unused then
+// level 1 / 2: redo the previous level's bin selection, histogram the next key bits of the
+// background cells inside the selected prefix
+template <int LEVEL>
+__global__ __launch_bounds__(HNM_T) void hnm_hist_kernel(const float* __restrict__ ce, const int32_t* __restrict__ labels,
+                                                         int64_t n_cells, int chunks, int ratio, void* ws_) {
+    constexpr int BINS = LEVEL == 1 ? HNM_B1 : HNM_B2;
+    __shared__ int hist[BINS];
+    __shared__ int sh[260];
+    const HnmWs ws = hnm_ws(ws_, chunks);
+    const int tid = threadIdx.x;
+    bool all_bg;
+    const long long num_bg = hnm_num_bg(ws.counts, ratio, all_bg);
+    if (all_bg || num_bg <= 0) return;
+    unsigned prefix;     // the key bits fixed so far, right-aligned
+    if (LEVEL == 1) {
+        int b0; long long k1;
+        hnm_select(ws.hist0, HNM_B0, num_bg, sh, b0, k1);
+        if (blockIdx.x == 0 && tid == 0) { ws.counts[2] = b0; ws.counts[3] = (int)k1; }
+        prefix = (unsigned)b0;
+    } else {
+        const int b0 = ws.counts[2];
+        int b1; long long k2;
+        hnm_select(ws.hist1, HNM_B1, (long long)ws.counts[3], sh, b1, k2);
+        if (blockIdx.x == 0 && tid == 0) { ws.counts[4] = b1; ws.counts[5] = (int)k2; }
+        prefix = ((unsigned)b0 << 11) | (unsigned)b1;
+    }
+    for (int i = tid; i < BINS; i += HNM_T) hist[i] = 0;
+    __syncthreads();
+    const int64_t base = (int64_t)blockIdx.x * HNM_CHUNK;
+#pragma unroll
+    for (int u = 0; u < HNM_CHUNK / HNM_T; ++u) {
+        const int64_t i = base + u * HNM_T + tid;
+        if (i < n_cells && labels[i] == 0) {
+            const unsigned key = sortable(ce[i]);
+            if (LEVEL == 1) {
+                if ((key >> 21) == prefix) atomicAdd(&hist[(key >> 10) & 2047], 1);
+            } else {
+                if ((key >> 10) == prefix) atomicAdd(&hist[key & 1023], 1);
+            }
+        }
+    }
+    __syncthreads();
+    int* out = LEVEL == 1 ? ws.hist1 : ws.hist2;
+    for (int i = tid; i < BINS; i += HNM_T)
+        if (hist[i]) atomicAdd(&out[i], hist[i]);
+}
+
+// threshold key and the number of cells equal to it that are selected; per-chunk tie counts
+__global__ __launch_bounds__(HNM_T) void hnm_tie_kernel(const float* __restrict__ ce, const int32_t* __restrict__ labels,
+                                                        int64_t n_cells, int chunks, int ratio, void* ws_) {
+    __shared__ int sh[260];
+    __shared__ int shi[4];
+    const HnmWs ws = hnm_ws(ws_, chunks);
+    const int tid = threadIdx.x;
+    bool all_bg;
+    const long long num_bg = hnm_num_bg(ws.counts, ratio, all_bg);
+    if (all_bg || num_bg <= 0) return;
+    int b2; long long k_eq;
+    hnm_select(ws.hist2, HNM_B2, (long long)ws.counts[5], sh, b2, k_eq);
+    const unsigned thr = ((unsigned)ws.counts[2] << 21) | ((unsigned)ws.counts[4] << 10) | (unsigned)b2;
+    if (blockIdx.x == 0 && tid == 0) { ws.counts[6] = (int)thr; ws.counts[7] = (int)k_eq; }
+    int ties = 0;
+    const int64_t base = (int64_t)blockIdx.x * HNM_CHUNK;
+#pragma unroll
+    for (int u = 0; u < HNM_CHUNK / HNM_T; ++u) {
+        const int64_t i = base + u * HNM_T + tid;
+        if (i < n_cells && labels[i] == 0 && sortable(ce[i]) == thr) ++ties;
+    }
+    ties = block_sum_i256(ties, shi);
+    if (tid == 0) ws.tie_cnt[blockIdx.x] = ties;
+}
+
+// per-cell weights (1/nfg, 1/num_bg or 0) and the per-chunk sums of the selected background ce
+__global__ __launch_bounds__(HNM_T) void hnm_weight_kernel(const float* __restrict__ ce, const int32_t* __restrict__ labels,
+                                                           int64_t n_cells, int chunks, int ratio, void* ws_,
+                                                           float* __restrict__ weight) {
+    __shared__ int shi[4];
+    __shared__ float shf[4];
+    __shared__ int wave_cnt[4];
+    const HnmWs ws = hnm_ws(ws_, chunks);
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    bool all_bg;
+    const long long num_bg = hnm_num_bg(ws.counts, ratio, all_bg);
+    const bool select = !all_bg && num_bg > 0;
+    const unsigned thr = select ? (unsigned)ws.counts[6] : 0u;
+    const long long k_eq = select ? (long long)ws.counts[7] : 0;
+    // cells equal to thr in earlier chunks (index order)
+    long long before_chunk = 0;
+    if (select) {
+        int part = 0;
+        for (int c = tid; c < (int)blockIdx.x; c += HNM_T) part += ws.tie_cnt[c];
+        before_chunk = block_sum_i256(part, shi);
+    }
+    const float w_fg = 1.f / (float)ws.counts[0];          // inf when nfg == 0; unused then
     const float w_bg = 1.f / (float)num_bg;
     float sum_sel = 0.f;
-    if (tid == 0) s_base = 0;
-    __syncthreads();
-    for (int64_t i0 = 0; i0 < n_cells; i0 += HNM_T) {
-        const int64_t i = i0 + tid;
+    const int64_t base = (int64_t)blockIdx.x * HNM_CHUNK;
+    for (int u = 0; u < HNM_CHUNK / HNM_T; ++u) {
+        const int64_t i = base + u * HNM_T + tid;
         const bool in = i < n_cells;
         const int lab = in ? labels[i] : 1;
         const float c = in ? ce[i] : 0.f;
@@ -178,28 +317,24 @@ __global__ __launch_bounds__(HNM_T) void hnm_kernel(const float* __restrict__ ce
         if (bg && num_bg > 0) {
             if (all_bg) take = true;
             else {
-                const unsigned u = sortable(c);
-                take = u > thr;
-                eq = u == thr;
+                const unsigned key = sortable(c);
+                take = key > thr;
+                eq = key == thr;
             }
         }
-        if (!all_bg && num_bg > 0) {
-            // ordinal of this cell among the cells equal to thr, in index order
+        if (select) {      // ordinal of this cell among the cells equal to thr, in index order
             const unsigned long long bal = __ballot(eq);
-            const int lane = tid & 63, wv = tid >> 6;
             const int before = __popcll(bal & ((1ull << lane) - 1ull));
             __syncthreads();
-            if (lane == 0) shi[wv] = __popcll(bal);
+            if (lane == 0) wave_cnt[wv] = __popcll(bal);
             __syncthreads();
             int wave_off = 0, total = 0;
-            for (int w = 0; w < HNM_T / 64; ++w) {
-                if (w < wv) wave_off += shi[w];
-                total += shi[w];
+            for (int w = 0; w < 4; ++w) {
+                if (w < wv) wave_off += wave_cnt[w];
+                total += wave_cnt[w];
             }
-            const int base = s_base;
-            if (eq && (long long)(base + wave_off + before) < k_eq) take = true;
-            __syncthreads();
-            if (tid == 0) s_base = base + total;
+            if (eq && before_chunk + wave_off + before < k_eq) take = true;
+            before_chunk += total;
         }
         if (in) {
             float w = 0.f;
@@ -208,13 +343,21 @@ __global__ __launch_bounds__(HNM_T) void hnm_kernel(const float* __restrict__ ce
             weight[i] = w;
         }
     }
-    sum_sel = block_sum_f(sum_sel, shf);
-    if (tid == 0) {
-        // mean over an empty set is NaN (tf.reduce_mean of an empty tensor): 0/0
-        loss_out[0] = sum_fg / (float)nfg + sum_sel / (float)num_bg;
-        loss_out[1] = (float)nfg;
-        loss_out[2] = (float)num_bg;
-    }
+    sum_sel = block_sum_f256(sum_sel, shf);
+    if (tid == 0) ws.sum_sel[blockIdx.x] = sum_sel;
+}
+
+__global__ __launch_bounds__(64) void hnm_final_kernel(int chunks, int ratio, void* ws_, float* __restrict__ loss_out) {
+    const HnmWs ws = hnm_ws(ws_, chunks);
+    if (threadIdx.x != 0) return;
+    bool all_bg;
+    const long long num_bg = hnm_num_bg(ws.counts, ratio, all_bg);
+    float sum_fg = 0.f, sum_sel = 0.f;
+    for (int c = 0; c < chunks; ++c) { sum_fg += ws.sum_fg[c]; sum_sel += ws.sum_sel[c]; }
+    // mean over an empty set is NaN (tf.reduce_mean of an empty tensor): 0/0
+    loss_out[0] = sum_fg / (float)ws.counts[0] + sum_sel / (float)num_bg;
+    loss_out[1] = (float)ws.counts[0];
+    loss_out[2] = (float)num_bg;
 }
 
 }  // namespace
@@ -235,15 +378,33 @@ extern "C" int cutie_softmax_ce_fwd(const void* logits, int ld, int dtype, const
     return CUTIE_OK;
 }
 
-extern "C" size_t cutie_hnm_workspace_bytes(int64_t) { return 16; }
+static inline int64_t hnm_chunks(int64_t n_cells) { return n_cells > 0 ? cutie::cdiv(n_cells, HNM_CHUNK) : 1; }
+
+extern "C" size_t cutie_hnm_workspace_bytes(int64_t n_cells) {
+    return (size_t)(HNM_INT_HEAD + 3 * hnm_chunks(n_cells)) * 4 + 64;
+}
 
 extern "C" int cutie_hnm_weights(const float* ce, const int32_t* labels, int64_t n_cells, int ratio, float* weight,
-                                 float* loss_out, void* /*workspace*/, size_t /*workspace_bytes*/,
-                                 cutie_stream_t stream_) {
+                                 float* loss_out, void* workspace, size_t workspace_bytes, cutie_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     CUTIE_CHECK_ARG(n_cells >= 0 && ratio >= 0, "hnm_weights: n=%lld ratio=%d", (long long)n_cells, ratio);
     CUTIE_CHECK_ARG(ce && labels && weight && loss_out, "hnm_weights: null pointer");
-    hipLaunchKernelGGL(hnm_kernel, dim3(1), dim3(HNM_T), 0, stream, ce, labels, n_cells, ratio, weight, loss_out);
+    CUTIE_CHECK_ARG(n_cells < (1ll << 31) - HNM_CHUNK, "hnm_weights: too many cells");
+    const size_t need = cutie_hnm_workspace_bytes(n_cells);
+    if (!workspace || workspace_bytes < need) {
+        cutie::set_error("hnm_weights: workspace %zu < %zu", workspace_bytes, need);
+        return CUTIE_E_WORKSPACE;
+    }
+    void* ws = (void*)(((uintptr_t)workspace + 15) & ~(uintptr_t)15);
+    const int chunks = (int)hnm_chunks(n_cells);
+    CUTIE_CHECK_HIP(hipMemsetAsync(ws, 0, (size_t)(HNM_INT_HEAD + 3 * chunks) * 4, stream));
+    const dim3 g(chunks), t(HNM_T);
+    hipLaunchKernelGGL(hnm_count_kernel, g, t, 0, stream, ce, labels, n_cells, chunks, ws);
+    hipLaunchKernelGGL(hnm_hist_kernel<1>, g, t, 0, stream, ce, labels, n_cells, chunks, ratio, ws);
+    hipLaunchKernelGGL(hnm_hist_kernel<2>, g, t, 0, stream, ce, labels, n_cells, chunks, ratio, ws);
+    hipLaunchKernelGGL(hnm_tie_kernel, g, t, 0, stream, ce, labels, n_cells, chunks, ratio, ws);
+    hipLaunchKernelGGL(hnm_weight_kernel, g, t, 0, stream, ce, labels, n_cells, chunks, ratio, ws, weight);
+    hipLaunchKernelGGL(hnm_final_kernel, dim3(1), dim3(64), 0, stream, chunks, ratio, ws, loss_out);
     CUTIE_CHECK_LAUNCH();
     return CUTIE_OK;
 }

@@ -177,9 +177,15 @@ def softmax_ce_fwd(logits, labels, C, ce, probs, bad):
          ptr(probs), ptr(bad), stream())
 
 
-def hnm_weights(ce, labels, ratio, weight, loss_out):
+def hnm_workspace_bytes(n_cells):
+    return capi.lib().cutie_hnm_workspace_bytes(n_cells)
+
+
+def hnm_weights(ce, labels, ratio, weight, loss_out, workspace=None):
+    if workspace is None:
+        workspace = torch.empty(hnm_workspace_bytes(labels.numel()), dtype=torch.uint8, device=ce.device)
     call("cutie_hnm_weights", ptr(ce), ptr(labels), labels.numel(), int(ratio), ptr(weight), ptr(loss_out),
-         None, 0, stream())
+         ptr(workspace), workspace.numel(), stream())
 
 
 def softmax_ce_bwd(probs, labels, weight, C, dlogits):

@@ -220,6 +220,7 @@ class Engine(object):
             ws_bytes = max(ws_bytes, ops.conv_wgrad_workspace_bytes(B, P.H, P.W, a["cin"], n.channels, a["kh"], a["kw"]))
         P.wgrad_ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
         P.scratch = torch.zeros(capi.REDUCE_SCRATCH, dtype=torch.float32, device=dev)
+        P.hnm_ws = torch.empty(ops.hnm_workspace_bytes(B * P.H * P.W), dtype=torch.uint8, device=dev)
         P.reg = torch.zeros(1, dtype=torch.float32, device=dev)
         P.gnorm_sq = torch.zeros(1, dtype=torch.float32, device=dev)
         P.bwd_ready = True
@@ -342,7 +343,7 @@ class Engine(object):
         net, spec = self.net, self.net.loss_spec
         lname = net.loss_logits_name
         C = self.C
-        ops.hnm_weights(P.ce, P.labels, int(spec["hard_negative_ratio"]), P.weight, P.loss)
+        ops.hnm_weights(P.ce, P.labels, int(spec["hard_negative_ratio"]), P.weight, P.loss, P.hnm_ws)
         ops.softmax_ce_bwd(P.probs, P.labels, P.weight, C, P.dy[lname][..., :C])
         self.grads_flat.zero_()
         P.red_all.zero_()
