@@ -12,9 +12,35 @@ using namespace cutie;
 
 template <int VEC> struct vecf { float v[VEC]; };
 
+__device__ __forceinline__ void load8(const float* p, float* v) {
+    const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+}
+__device__ __forceinline__ void load8(const bf16_t* p, float* v) {
+    const uint4 u = *reinterpret_cast<const uint4*>(p);
+    v[0] = __uint_as_float(u.x << 16); v[1] = __uint_as_float(u.x & 0xffff0000u);
+    v[2] = __uint_as_float(u.y << 16); v[3] = __uint_as_float(u.y & 0xffff0000u);
+    v[4] = __uint_as_float(u.z << 16); v[5] = __uint_as_float(u.z & 0xffff0000u);
+    v[6] = __uint_as_float(u.w << 16); v[7] = __uint_as_float(u.w & 0xffff0000u);
+}
+__device__ __forceinline__ void store8(float* p, const float* v) {
+    *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+    *reinterpret_cast<float4*>(p + 4) = make_float4(v[4], v[5], v[6], v[7]);
+}
+__device__ __forceinline__ void store8(bf16_t* p, const float* v) {
+    uint4 u;
+    u.x = static_cast<unsigned>(f2bf(v[0])) | (static_cast<unsigned>(f2bf(v[1])) << 16);
+    u.y = static_cast<unsigned>(f2bf(v[2])) | (static_cast<unsigned>(f2bf(v[3])) << 16);
+    u.z = static_cast<unsigned>(f2bf(v[4])) | (static_cast<unsigned>(f2bf(v[5])) << 16);
+    u.w = static_cast<unsigned>(f2bf(v[6])) | (static_cast<unsigned>(f2bf(v[7])) << 16);
+    *reinterpret_cast<uint4*>(p) = u;
+}
+
 template <int VEC, typename T> __device__ __forceinline__ vecf<VEC> loadv(const T* p) {
     vecf<VEC> r;
-    if constexpr (VEC == 4) {
+    if constexpr (VEC == 8) {
+        load8(p, r.v);
+    } else if constexpr (VEC == 4) {
         const float4 f = load4(p);
         r.v[0] = f.x; r.v[1] = f.y; r.v[2] = f.z; r.v[3] = f.w;
     } else {
@@ -23,7 +49,9 @@ template <int VEC, typename T> __device__ __forceinline__ vecf<VEC> loadv(const 
     return r;
 }
 template <int VEC, typename T> __device__ __forceinline__ void storev(T* p, const vecf<VEC>& r) {
-    if constexpr (VEC == 4) {
+    if constexpr (VEC == 8) {
+        store8(p, r.v);
+    } else if constexpr (VEC == 4) {
         store4(p, make_float4(r.v[0], r.v[1], r.v[2], r.v[3]));
     } else {
         store_from_f32(p, r.v[0]);
@@ -60,16 +88,13 @@ __device__ __forceinline__ void mean_inv(const float* stats, int b, int C, int c
 template <int VEC, int NRED, typename F>
 __device__ __forceinline__ void block_reduce_atomic(float (*red)[256][VEC], const Map& m, int CV, F&& dst) {
     __syncthreads();
-    if (threadIdx.x < CV) {
-#pragma unroll
-        for (int k = 0; k < NRED; ++k) {
-#pragma unroll
-            for (int e = 0; e < VEC; ++e) {
-                float s = 0.f;
-                for (int r = 0; r < m.rows_par; ++r) s += red[k][r * CV + threadIdx.x][e];
-                atomicAdd(dst(threadIdx.x * VEC + e, k), s);
-            }
-        }
+    const int C = CV * VEC;
+    for (int idx = threadIdx.x; idx < NRED * C; idx += 256) {      // all lanes share the tail
+        const int k = idx / C, c = idx - k * C;
+        const int cl = c / VEC, e = c - cl * VEC;
+        float s = 0.f;
+        for (int r = 0; r < m.rows_par; ++r) s += red[k][r * CV + cl][e];
+        atomicAdd(dst(c, k), s);
     }
 }
 
@@ -127,6 +152,7 @@ __global__ __launch_bounds__(256) void in_bwd_stats_kernel(const TD* __restrict_
         float mean[VEC], inv[VEC];
 #pragma unroll
         for (int e = 0; e < VEC; ++e) mean_inv(stats, m.b, C, m.cl * VEC + e, inv_n, eps, mean[e], inv[e]);
+#pragma unroll 4
         for (int hw = m.hw0 + m.sub; hw < m.hw1; hw += m.rows_par) {
             const int64_t row = (int64_t)m.b * HW + hw;
             const vecf<VEC> g = loadv<VEC>(dy + row * ld_dy + m.cl * VEC);
@@ -242,7 +268,9 @@ inline int pick_vec(int C, std::initializer_list<int> lds, std::initializer_list
     if (C % 4) return 1;
     for (int l : lds) if (l % 4) return 1;
     for (const void* p : ptrs) if (p && ((uintptr_t)p % 16)) return 1;
-    return 4;
+    if (C % 8 || C < 64) return 4;
+    for (int l : lds) if (l % 8) return 4;
+    return 8;      // 16-byte (bf16) / 32-byte (f32) accesses per lane
 }
 inline int check_common(const char* name, int B, int HW, int C, int vec) {
     if (B < 0 || HW < 1 || C < 1) { cutie::set_error("%s: bad sizes B=%d HW=%d C=%d", name, B, HW, C); return CUTIE_E_ARG; }
@@ -252,7 +280,7 @@ inline int check_common(const char* name, int B, int HW, int C, int vec) {
 inline dim3 reduce_grid(int B, int HW, int C, int vec) {
     const int rows_par = 256 / (C / vec);
     int s = HW / (rows_par * 8);
-    const int cap = (2048 + B - 1) / (B > 0 ? B : 1);
+    const int cap = (1024 + B - 1) / (B > 0 ? B : 1);
     if (s > cap) s = cap;
     if (s < 1) s = 1;
     return dim3(s, B);
@@ -261,7 +289,8 @@ inline dim3 reduce_grid(int B, int HW, int C, int vec) {
 }  // namespace
 
 #define NORM_DISPATCH_VEC(vec, ...)                                   \
-    if ((vec) == 4) { constexpr int VEC = 4; __VA_ARGS__; }           \
+    if ((vec) == 8) { constexpr int VEC = 8; __VA_ARGS__; }           \
+    else if ((vec) == 4) { constexpr int VEC = 4; __VA_ARGS__; }      \
     else { constexpr int VEC = 1; __VA_ARGS__; }
 
 extern "C" int cutie_in_stats(const void* a, int ld_a, int a_dtype, int B, int HW, int C, float* stats,
