@@ -52,6 +52,11 @@ class ConvTimer(object):
         self.events, self.flops, self.enabled = [], [], False
         ops.conv_fwd = self
 
+    # Timing events serialise the queue (each one is a barrier packet): bracketing all 28 conv
+    # launches of every step costs ~6 % of the step.  So only every EVERY-th timed step is
+    # instrumented; `value` stays within ~1 % of an uninstrumented run.
+    EVERY = 5
+
     def __call__(self, segs, out, n_out, **kw):
         if not self.enabled:
             return self.orig(segs, out, n_out, **kw)
@@ -144,9 +149,9 @@ def main():
     for _ in range(args.warmup):
         step()
     fence()
-    timer.enabled = not args.no_kernel_timing
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for k in range(args.steps):
+        timer.enabled = (not args.no_kernel_timing) and k % ConvTimer.EVERY == 0
         step()
     fence()
     dt = time.perf_counter() - t0
@@ -176,7 +181,8 @@ def main():
                                "frac": round(ach / peak, 4), "traffic": None,
                                "kernel": "conv_wide_kernel + conv_kernel (forward + data-gradient implicit GEMM)", "launches": n,
                                "avg_launch_ms": round(ms / max(n, 1), 4),
-                               "share_of_step": round(ms / (1e3 * dt), 4)}
+                               "timed_steps": "every %d-th of the %d timed steps" % (ConvTimer.EVERY, args.steps),
+                               "share_of_step": round(ms / max(1, -(-args.steps // ConvTimer.EVERY)) / (1e3 * dt / args.steps), 4)}
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(C, V, E, H, W, packed)
         print(json.dumps(out), flush=True)

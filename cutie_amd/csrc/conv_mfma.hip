@@ -467,7 +467,17 @@ __global__ __launch_bounds__(WG5_NT, 2) void wgrad5_kernel(Wgrad5Params p) {
     const int li = lane & 15, lg = lane >> 4;
     const int H = p.H, W = p.W, dil = p.dil, pad = p.pad;
 
-    int bid = blockIdx.x;
+    // Workgroups that multiply the SAME pixels (one K split; different tap row / channel tiles)
+    // should meet in one L2: hardware deals consecutive ids round-robin over the 8 XCDs, so give
+    // each XCD a contiguous run of logical ids (bijective for any grid size) and make the K split
+    // the slow index of the logical id.
+    const int groups = p.kh * p.mt * p.ntile;
+    const int nwg = groups * p.splits;
+    const int hw_id = blockIdx.x;
+    const int qx = nwg >> 3, rx = nwg & 7, xcd = hw_id & 7;
+    const int logical = (xcd < rx ? xcd * (qx + 1) : rx * (qx + 1) + (xcd - rx) * qx) + (hw_id >> 3);
+    const int split = logical / groups;
+    int bid = logical - split * groups;
     const int nt = bid % p.ntile; bid /= p.ntile;
     const int mt = bid % p.mt;
     const int ti = bid / p.mt;                 // tap row
@@ -476,7 +486,7 @@ __global__ __launch_bounds__(WG5_NT, 2) void wgrad5_kernel(Wgrad5Params p) {
 
     const int units_total = p.B * H * p.nwseg;  // a unit = (sample, image row, 64-pixel column segment)
     const int per = (units_total + p.splits - 1) / p.splits;
-    const int unit_begin = blockIdx.y * per;
+    const int unit_begin = split * per;
     const int unit_end = min(units_total, unit_begin + per);
 
     float4_t acc[KW][2][4];
@@ -624,7 +634,7 @@ __global__ __launch_bounds__(WG5_NT, 2) void wgrad5_kernel(Wgrad5Params p) {
 
 #pragma unroll
     for (int t = 0; t < KW; ++t) {
-        float* slab = p.slabs + ((long long)blockIdx.y * p.kh * KW + (ti * KW + t)) * p.cin * p.cout;
+        float* slab = p.slabs + ((long long)split * p.kh * KW + (ti * KW + t)) * p.cin * p.cout;
 #pragma unroll
         for (int m = 0; m < 2; ++m)
 #pragma unroll
@@ -820,7 +830,7 @@ extern "C" int cutie_conv_wgrad(const void* x, int ld_x, int cin, const void* dz
                         if (!(px0 + sx + 31 < 0 || px0 + sx >= W)) mask |= 1 << (ks * kw + t);
                     }
             }
-            const dim3 grid5(kh * q.mt * q.ntile, q.splits);
+            const dim3 grid5(kh * q.mt * q.ntile * q.splits);
 #define CUTIE_WG5_LAUNCH(KW_, MASK_)                                                                              \
     do {                                                                                                          \
         CUTIE_CHECK_HIP(hipFuncSetAttribute((const void*)wgrad5_kernel<KW_, MASK_>,                               \
