@@ -177,8 +177,16 @@ def main():
             ms, fl, n = timer.summary()
             ach = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
             peak = BF16_PEAK_TFLOPS if args.dtype == "bf16" else 157.3
+            traffic, traffic_src = None, None
+            pmc = os.path.join(REPO, "profiles", "r01_d_pmc_traffic.json")
+            if args.dtype == "bf16" and os.path.exists(pmc):      # PMC passes cannot run inside the timed bench
+                with open(pmc) as f:
+                    k = json.load(f)["kernels"].get("conv_wide_kernel")
+                if k:
+                    traffic = k["hbm_bytes_per_launch"]
+                    traffic_src = "profiles/r01_d_pmc_traffic.json: (2*FETCH_SIZE + WRITE_SIZE)*1024 per conv_wide_kernel launch"
             out["roofline"] = {"bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
-                               "frac": round(ach / peak, 4), "traffic": None,
+                               "frac": round(ach / peak, 4), "traffic": traffic, "traffic_source": traffic_src,
                                "kernel": "conv_wide_kernel + conv_kernel (forward + data-gradient implicit GEMM)", "launches": n,
                                "avg_launch_ms": round(ms / max(n, 1), 4),
                                "timed_steps": "every %d-th of the %d timed steps" % (ConvTimer.EVERY, args.steps),

@@ -17,6 +17,7 @@
 //   * a tap whose shifted tile lies wholly outside the image is not a step at all (uniform for
 //     the workgroup), which keeps the in-bounds FLOP accounting for 16-aligned dilations.
 #include "conv_common.h"
+#include <stdlib.h>
 
 namespace cutie {
 namespace {
@@ -25,6 +26,60 @@ using namespace cutie::convk;
 constexpr int CW_NT = 512;
 constexpr int CW_A0 = 0, CW_B0 = 65536, CW_BUF = 32768;    // LDS map: A0 A1 B0 B1, 32 KB each
 constexpr int CW_LDS = 131072;
+
+// bias, ReLU, instance-norm moments, LDS-staged coalesced store of a 256-pixel x 256-channel tile
+__device__ __forceinline__ void conv_wide_epilogue(const ConvParams& p, float4_t (&acc)[8][4], char* smem, int b, int h0,
+                                                   int w0, int n0) {
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    const int li = lane & 15, lg = lane >> 4;
+    const int H = p.H, W = p.W, TCB = p.TWB, n_out = p.n_out;
+    __syncthreads();
+    bf16_t* Cs = reinterpret_cast<bf16_t*>(smem);  // [256 pixels][256 channels]
+#pragma unroll
+    for (int n = 0; n < 4; ++n) {
+        const int cl = wn * 64 + n * 16 + li;
+        const int col = n0 + cl;
+        const float bv = (p.bias && col < n_out) ? p.bias[col] : 0.f;
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int m = 0; m < 8; ++m) {
+            const int mb = wm * 8 + m;
+            const int h = h0 + mb / TCB;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int w = w0 + (mb % TCB) * 16 + lg * 4 + r;
+                float v = acc[m][n][r] + bv;
+                if (p.relu) v = fmaxf(v, 0.f);
+                if (!(h < H && w < W)) v = 0.f;
+                s1 += v;
+                s2 += v * v;
+                Cs[(mb * 16 + lg * 4 + r) * 256 + cl] = f2bf(v);
+            }
+        }
+        if (p.stats) {
+            s1 += __shfl_xor(s1, 16, 64); s1 += __shfl_xor(s1, 32, 64);
+            s2 += __shfl_xor(s2, 16, 64); s2 += __shfl_xor(s2, 32, 64);
+            if (lg == 0 && col < n_out) {
+                atomicAdd(p.stats + ((long long)b * n_out + col) * 2 + 0, s1);
+                atomicAdd(p.stats + ((long long)b * n_out + col) * 2 + 1, s2);
+            }
+        }
+    }
+    __syncthreads();
+    for (int idx = tid; idx < 256 * 32; idx += CW_NT) {      // 16-byte pieces: 32 per pixel row
+        const int ml = idx >> 5, pc = idx & 31;
+        const int mb = ml >> 4;
+        const int h = h0 + mb / TCB, w = w0 + (mb % TCB) * 16 + (ml & 15);
+        const int col = n0 + pc * 8;
+        if (h < H && w < W && col < n_out) {
+            bf16_t* dst = reinterpret_cast<bf16_t*>(p.out) + ((long long)(b * H + h) * W + w) * p.ld_out + col;
+            *reinterpret_cast<uint4*>(dst) = *reinterpret_cast<const uint4*>(Cs + ml * 256 + pc * 8);
+        }
+    }
+}
 
 __global__ __launch_bounds__(CW_NT) void conv_wide_kernel(ConvParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -200,51 +255,9 @@ __global__ __launch_bounds__(CW_NT) void conv_wide_kernel(ConvParams p) {
         buf ^= 1;
     }
 
-    // ---- epilogue: bias, ReLU, instance-norm moments, LDS-staged coalesced store
-    __syncthreads();
-    bf16_t* Cs = reinterpret_cast<bf16_t*>(smem);  // [256 pixels][256 channels]
-#pragma unroll
-    for (int n = 0; n < 4; ++n) {
-        const int cl = wn * 64 + n * 16 + li;
-        const int col = n0 + cl;
-        const float bv = (p.bias && col < n_out) ? p.bias[col] : 0.f;
-        float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-        for (int m = 0; m < 8; ++m) {
-            const int mb = wm * 8 + m;
-            const int h = h0 + mb / TCB;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int w = w0 + (mb % TCB) * 16 + lg * 4 + r;
-                float v = acc[m][n][r] + bv;
-                if (p.relu) v = fmaxf(v, 0.f);
-                if (!(h < H && w < W)) v = 0.f;
-                s1 += v;
-                s2 += v * v;
-                Cs[(mb * 16 + lg * 4 + r) * 256 + cl] = f2bf(v);
-            }
-        }
-        if (p.stats) {
-            s1 += __shfl_xor(s1, 16, 64); s1 += __shfl_xor(s1, 32, 64);
-            s2 += __shfl_xor(s2, 16, 64); s2 += __shfl_xor(s2, 32, 64);
-            if (lg == 0 && col < n_out) {
-                atomicAdd(p.stats + ((long long)b * n_out + col) * 2 + 0, s1);
-                atomicAdd(p.stats + ((long long)b * n_out + col) * 2 + 1, s2);
-            }
-        }
-    }
-    __syncthreads();
-    for (int idx = tid; idx < 256 * 32; idx += CW_NT) {      // 16-byte pieces: 32 per pixel row
-        const int ml = idx >> 5, pc = idx & 31;
-        const int mb = ml >> 4;
-        const int h = h0 + mb / TCB, w = w0 + (mb % TCB) * 16 + (ml & 15);
-        const int col = n0 + pc * 8;
-        if (h < H && w < W && col < n_out) {
-            bf16_t* dst = reinterpret_cast<bf16_t*>(p.out) + ((long long)(b * H + h) * W + w) * p.ld_out + col;
-            *reinterpret_cast<uint4*>(dst) = *reinterpret_cast<const uint4*>(Cs + ml * 256 + pc * 8);
-        }
-    }
+    conv_wide_epilogue(p, acc, smem, b, h0, w0, n0);
 }
+
 
 }  // namespace
 
