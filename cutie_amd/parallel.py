@@ -32,6 +32,7 @@ class GradBuckets(object):
 
     def __init__(self, flat, n_front, n_buckets=4, group=None, align=64):
         self.flat, self.group = flat, group
+        self._drain_first = None
         self.n_front = int(n_front)
         step = max(align, (self.n_front // max(1, n_buckets) + align - 1) // align * align)
         self.bounds = list(range(step, self.n_front, step)) + [self.n_front]
@@ -42,6 +43,13 @@ class GradBuckets(object):
 
     def _launch(self, lo, hi):
         if hi > lo:
+            if self._drain_first is None:
+                # gloo moves device tensors through the host on its own threads and was seen to
+                # dead-lock when further kernels pile up behind an un-drained stream (two ranks
+                # sharing one GPU in the tests); RCCL enqueues on its own stream and needs nothing
+                self._drain_first = self.flat.is_cuda and dist.get_backend(self.group) == "gloo"
+            if self._drain_first:
+                torch.cuda.current_stream(self.flat.device).synchronize()
             self.works.append(dist.all_reduce(self.flat[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
     def ready(self, upto):

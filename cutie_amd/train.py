@@ -59,4 +59,4 @@ class Trainer(object):
             return None
         ml, rg, tl = eng.losses(P)
         return {"model_loss": ml, "regularization_loss": rg, "total_loss": tl,
-                "logits": eng.get(P, "cls_logits"), "softmax": P.probs, "global_norm": math.sqrt(float(gn.item()))}
+                "logits": eng.get(P, "cls_logits"), "softmax": P.probs, "global_norm": math.sqrt(float(gn.item())) / self.world}      # of the mean gradient: what the clip sees
