@@ -22,6 +22,7 @@ Outputs
   synthetic_grids.json/npz  a2: seeded synthetic docs incl. crowded rows (shift-left), id 0
   tokenizer_cases.json      tokenization.FullTokenizer splits + the vocab subset they need
   shapes.json               a3: _cal_rows_cols / natural shapes
+  accuracy_cases.json/npz   f2: utils.cal_accuracy on the Faktura1 64x64 grid and seeded model outputs
   invoice/Faktura1.pdf_0.json  copy of the reference's own sample input (data file)
 """
 import hashlib
@@ -335,6 +336,35 @@ def main():
     shapes["augment_strategy1"] = aug
     with open(os.path.join(HERE, "shapes.json"), "w") as f:
         json.dump(shapes, f)
+
+    # ---------------------------------------------------------------- f2: utils.cal_accuracy
+    import utils as ref_utils
+    loader.pm_strategy = 1
+    r = run_mapping(loader, loader.training_docs[:1], loader.training_labels, 64, 64, 1)
+    grid_table = r["grid"].reshape(1, 64, 64, 1)
+    gt = r["labels"].astype(np.int64).reshape(1, 64, 64)
+    rs = np.random.RandomState(5)
+    acc_cases = []
+    for case, (flip, noise) in enumerate([(0.0, 0.02), (0.15, 0.03), (0.5, 0.04), (0.03, 0.0)]):
+        # a softmax-like output: one-hot of the labels, a share of the labelled cells flipped to
+        # another class, uniform noise, renormalised
+        C = loader.num_classes
+        lab = gt.copy()
+        mask = (rs.rand(*lab.shape) < flip) & (grid_table[..., 0] != 0)
+        lab[mask] = rs.randint(0, C, size=int(mask.sum()))
+        out = np.eye(C)[lab] + noise * rs.rand(1, 64, 64, C)
+        out = (out / out.sum(-1, keepdims=True)).astype(np.float32)
+        prev, strict, soft, res = ref_utils.cal_accuracy(loader, grid_table, gt, out, r["label_mapids"], r["bbox_mapids"])
+        acc_cases.append({"flip": flip, "noise": noise, "prevalence": float(prev), "accuracy_strict": float(strict),
+                          "accuracy_soft": float(soft), "res": res.decode("utf-8")})
+        npz_acc = {"model_output_%d" % case: out}
+        syn_acc = npz_acc if case == 0 else {**syn_acc, **npz_acc}
+    np.savez_compressed(os.path.join(HERE, "accuracy_cases.npz"), grid_table=grid_table, gt_classes=gt, **syn_acc)
+    grid_ids = sorted(set(int(v) for v in grid_table.reshape(-1)))
+    with open(os.path.join(HERE, "accuracy_cases.json"), "w", encoding="utf-8") as f:
+        json.dump({"cases": acc_cases, "label_mapids": r["label_mapids"], "bbox_mapids": r["bbox_mapids"],
+                   "classes": list(loader.classes),
+                   "index_to_word": {str(i): loader.index_to_word[i] for i in grid_ids}}, f, ensure_ascii=False)
 
     print("golden fixtures written to", HERE)
     g = npz["r64c64s1_grid"]
