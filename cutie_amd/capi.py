@@ -14,7 +14,7 @@ MAX_SEGS = 6
 REDUCE_SCRATCH = 1024
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libcutie_hip.so")
+LIB_PATH = os.environ.get("CUTIE_HIP_LIB") or os.path.join(_HERE, "libcutie_hip.so")   # override: A/B builds
 
 
 class CutieError(RuntimeError):
