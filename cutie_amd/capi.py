@@ -27,6 +27,18 @@ class ConvSeg(ctypes.Structure):
                 ("dil", ctypes.c_int), ("flip", ctypes.c_int)]
 
 
+class PackDesc(ctypes.Structure):
+    _fields_ = [("w_hwio", ctypes.c_void_p), ("w_fwd", ctypes.c_void_p), ("w_dgrad", ctypes.c_void_p),
+                ("taps", ctypes.c_int), ("cin", ctypes.c_int), ("cout", ctypes.c_int),
+                ("cin_pad", ctypes.c_int), ("cout_pad", ctypes.c_int)]
+
+
+class SumRowsDesc(ctypes.Structure):
+    _fields_ = [("part", ctypes.c_void_p), ("out", ctypes.c_void_p), ("C", ctypes.c_int)]
+
+
+MAX_BATCH = 32
+
 _c = ctypes
 _vp, _i, _i64, _f, _sz = _c.c_void_p, _c.c_int, _c.c_int64, _c.c_float, _c.c_size_t
 
@@ -43,11 +55,13 @@ SIGNATURES = {
     "cutie_conv_wgrad_workspace_bytes": (_sz, [_i, _i, _i, _i, _i, _i, _i]),
     "cutie_conv_wgrad": (_i, [_vp, _i, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _i, _i, _vp, _sz, _vp]),
     "cutie_pack_weights": (_i, [_vp, _i, _i, _i, _vp, _i, _vp, _i, _i, _vp]),
+    "cutie_pack_weights_batched": (_i, [_c.POINTER(PackDesc), _i, _i, _vp]),
     "cutie_in_stats": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "cutie_in_apply": (_i, [_vp, _i, _i, _vp, _f, _vp, _i, _i, _i, _i, _i, _vp]),
     "cutie_in_bwd_stats": (_i, [_vp, _i, _i, _vp, _i, _i, _vp, _f, _vp, _i, _i, _i, _vp]),
     "cutie_in_bwd_apply": (_i, [_vp, _i, _i, _vp, _i, _i, _vp, _f, _vp, _i, _vp, _i, _i, _vp, _i, _i, _i, _vp]),
     "cutie_sum_rows": (_i, [_vp, _i, _i, _vp, _i, _vp]),
+    "cutie_sum_rows_batched": (_i, [_c.POINTER(SumRowsDesc), _i, _i, _i, _vp]),
     "cutie_spatial_mean_bcast": (_i, [_vp, _i, _i, _vp, _i, _i, _i, _i, _i, _vp]),
     "cutie_softmax_ce_fwd": (_i, [_vp, _i, _i, _vp, _i64, _i, _vp, _vp, _vp, _vp]),
     "cutie_hnm_workspace_bytes": (_sz, [_i64]),

@@ -369,6 +369,37 @@ extern "C" int cutie_sum_rows(const float* part, int B, int C, float* out, int a
     return CUTIE_OK;
 }
 
+namespace {
+struct SumRowsBatch {
+    cutie_sum_rows_desc d[CUTIE_MAX_BATCH];
+};
+__global__ __launch_bounds__(256) void sum_rows_batched_kernel(SumRowsBatch sb, int B, int accumulate) {
+    const cutie_sum_rows_desc d = sb.d[blockIdx.y];
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= d.C) return;
+    float s = accumulate ? d.out[c] : 0.f;
+    for (int b = 0; b < B; ++b) s += d.part[(int64_t)b * d.C + c];
+    d.out[c] = s;
+}
+}  // namespace
+
+extern "C" int cutie_sum_rows_batched(const cutie_sum_rows_desc* descs, int n, int B, int accumulate,
+                                      cutie_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    CUTIE_CHECK_ARG(n >= 0 && n <= CUTIE_MAX_BATCH && B >= 0 && (n == 0 || descs), "sum_rows_batched: n=%d B=%d", n, B);
+    if (n == 0) return CUTIE_OK;
+    SumRowsBatch sb;
+    int cmax = 0;
+    for (int i = 0; i < n; ++i) {
+        CUTIE_CHECK_ARG(descs[i].part && descs[i].out && descs[i].C >= 1, "sum_rows_batched: bad entry %d", i);
+        sb.d[i] = descs[i];
+        if (descs[i].C > cmax) cmax = descs[i].C;
+    }
+    hipLaunchKernelGGL(sum_rows_batched_kernel, dim3((cmax + 255) / 256, n), dim3(256), 0, stream, sb, B, accumulate);
+    CUTIE_CHECK_LAUNCH();
+    return CUTIE_OK;
+}
+
 extern "C" int cutie_spatial_mean_bcast(const void* x, int ld_x, int x_dtype, void* out, int ld_out, int out_dtype,
                                         int B, int HW, int C, cutie_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;

@@ -150,6 +150,61 @@ extern "C" int cutie_adam_step(float* p, const float* g, float* m, float* v, int
     return CUTIE_OK;
 }
 
+namespace {
+struct PackBatch {
+    cutie_pack_desc d[CUTIE_MAX_BATCH];
+};
+template <typename T>
+__global__ __launch_bounds__(256) void pack_batched_kernel(PackBatch pb) {
+    const cutie_pack_desc d = pb.d[blockIdx.y];
+    const float* __restrict__ w = d.w_hwio;
+    T* __restrict__ w_fwd = (T*)d.w_fwd;
+    T* __restrict__ w_dg = (T*)d.w_dgrad;
+    const int cin = d.cin, cout = d.cout, cin_pad = d.cin_pad, cout_pad = d.cout_pad;
+    const int64_t n_fwd = w_fwd ? (int64_t)d.taps * cout * cin_pad : 0;
+    const int64_t n_dg = w_dg ? (int64_t)d.taps * cin * cout_pad : 0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_fwd + n_dg;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        if (i < n_fwd) {
+            const int c = (int)(i % cin_pad);
+            const int64_t r = i / cin_pad;
+            const int n = (int)(r % cout);
+            const int t = (int)(r / cout);
+            store_from_f32(w_fwd + i, c < cin ? w[((int64_t)t * cin + c) * cout + n] : 0.f);
+        } else {
+            const int64_t j = i - n_fwd;
+            const int n = (int)(j % cout_pad);
+            const int64_t r = j / cout_pad;   // t*cin + c
+            store_from_f32(w_dg + j, n < cout ? w[r * cout + n] : 0.f);
+        }
+    }
+}
+}  // namespace
+
+extern "C" int cutie_pack_weights_batched(const cutie_pack_desc* descs, int n, int dtype, cutie_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    CUTIE_CHECK_ARG(n >= 0 && n <= CUTIE_MAX_BATCH && (n == 0 || descs), "pack_weights_batched: n=%d (0..%d)", n, CUTIE_MAX_BATCH);
+    if (n == 0) return CUTIE_OK;
+    PackBatch pb;
+    int64_t most = 0;
+    for (int i = 0; i < n; ++i) {
+        const cutie_pack_desc& d = descs[i];
+        CUTIE_CHECK_ARG(d.taps >= 1 && d.cin >= 1 && d.cout >= 1 && d.w_hwio, "pack_weights_batched: bad layer %d", i);
+        CUTIE_CHECK_ARG(!d.w_fwd || d.cin_pad >= d.cin, "pack_weights_batched: layer %d cin_pad < cin", i);
+        CUTIE_CHECK_ARG(!d.w_dgrad || d.cout_pad >= d.cout, "pack_weights_batched: layer %d cout_pad < cout", i);
+        pb.d[i] = d;
+        const int64_t total = (d.w_fwd ? (int64_t)d.taps * d.cout * d.cin_pad : 0) + (d.w_dgrad ? (int64_t)d.taps * d.cin * d.cout_pad : 0);
+        if (total > most) most = total;
+    }
+    if (most == 0) return CUTIE_OK;
+    int64_t gx = cutie::cdiv(most, 256 * 8);
+    if (gx > 1024) gx = 1024;
+    CUTIE_DISPATCH_DTYPE(dtype, DT,
+        hipLaunchKernelGGL(pack_batched_kernel<typename elem<DT>::type>, dim3((int)gx, n), dim3(256), 0, stream, pb));
+    CUTIE_CHECK_LAUNCH();
+    return CUTIE_OK;
+}
+
 extern "C" int cutie_pack_weights(const float* w_hwio, int taps, int cin, int cout, void* w_fwd, int cin_pad,
                                   void* w_dgrad, int cout_pad, int dtype, cutie_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;

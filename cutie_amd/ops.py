@@ -78,6 +78,51 @@ def pack_weights_into(w_hwio, dt, w_fwd, w_dg):
          dt, stream())
 
 
+def pack_weights_batched(entries, dt):
+    """entries: list of (w_hwio f32 [kh,kw,cin,cout], w_fwd or None, w_dgrad or None); one launch per
+    capi.MAX_BATCH layers.  Returns the descriptor arrays so that a caller can keep and replay them."""
+    batches = []
+    for lo in range(0, len(entries), capi.MAX_BATCH):
+        chunk = entries[lo:lo + capi.MAX_BATCH]
+        arr = (capi.PackDesc * len(chunk))()
+        for i, (w, wf, wd) in enumerate(chunk):
+            kh, kw, cin, cout = w.shape
+            if not w.is_contiguous() or w.dtype != torch.float32:
+                raise capi.CutieError("pack_weights_batched: weights must be contiguous f32 HWIO")
+            arr[i].w_hwio, arr[i].w_fwd, arr[i].w_dgrad = ptr(w), ptr(wf), ptr(wd)
+            arr[i].taps, arr[i].cin, arr[i].cout = kh * kw, cin, cout
+            arr[i].cin_pad = wf.shape[2] if wf is not None else 0
+            arr[i].cout_pad = wd.shape[2] if wd is not None else 0
+        batches.append(arr)
+    replay_pack(batches, dt)
+    return batches
+
+
+def replay_pack(batches, dt):
+    for arr in batches:
+        call("cutie_pack_weights_batched", arr, len(arr), dt, stream())
+
+
+def sum_rows_batched(entries, B, accumulate=False):
+    """entries: list of (part f32 [B,C], out f32 [C]).  Returns the descriptor arrays for replay."""
+    batches = []
+    for lo in range(0, len(entries), capi.MAX_BATCH):
+        chunk = entries[lo:lo + capi.MAX_BATCH]
+        arr = (capi.SumRowsDesc * len(chunk))()
+        for i, (part, out) in enumerate(chunk):
+            if part.shape[0] != B or part.shape[1] != out.numel() or not part.is_contiguous():
+                raise capi.CutieError("sum_rows_batched: entry %d shapes %s -> %s" % (i, tuple(part.shape), tuple(out.shape)))
+            arr[i].part, arr[i].out, arr[i].C = ptr(part), ptr(out), out.numel()
+        batches.append(arr)
+    replay_sum_rows(batches, B, accumulate)
+    return batches
+
+
+def replay_sum_rows(batches, B, accumulate=False):
+    for arr in batches:
+        call("cutie_sum_rows_batched", arr, len(arr), B, 1 if accumulate else 0, stream())
+
+
 def conv_fwd(segs, out, n_out, bias=None, relu=False, stats=None):
     """segs: list of dict(x=[B,H,W,>=cin] view, w=packed [taps, n_rows, cin], cin, kh, kw, dil, flip,
     n_off=row offset into w).  out: [B,H,W,>=n_out] view."""

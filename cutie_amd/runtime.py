@@ -112,8 +112,12 @@ class Engine(object):
         return OrderedDict((k, v.detach().cpu().numpy().copy()) for k, v in self.params.items())
 
     def repack(self):
-        for name in self.conv_w_names:
-            ops.pack_weights_into(self.params[name], self.dt, self.w_fwd[name], self.w_dg[name])
+        """params -> MFMA operand layouts, all layers in one launch (descriptors built once)."""
+        if getattr(self, "_pack_batches", None) is None:
+            self._pack_batches = ops.pack_weights_batched(
+                [(self.params[n], self.w_fwd[n], self.w_dg[n]) for n in self.conv_w_names], self.dt)
+        else:
+            ops.replay_pack(self._pack_batches, self.dt)
 
     # ------------------------------------------------------------------ planning
     def _plan(self, B, H, W, Hi):
@@ -359,7 +363,6 @@ class Engine(object):
                 ops.in_bwd_stats(dy, av, P.stats[n.name], P.red[n.name])
                 ops.in_bwd_apply(dy, av, P.stats[n.name], P.red[n.name], P.dz[n.name][..., :n.channels],
                                  dbias_part=P.dbpart[n.name], relu=True)
-                ops.sum_rows(P.dbpart[n.name], self.grads[n.name + "/biases"])
                 src = n.inputs[0]
                 ops.conv_wgrad(P.view(src.name, a["cin"]), a["cin"], P.dz[n.name][..., :n.channels], n.channels,
                                a["kh"], a["kw"], a["rate"], self.grads[n.name + "/weights"], P.wgrad_ws)
@@ -371,6 +374,12 @@ class Engine(object):
                 ops.conv_fwd(self._grad_segments(P, n.name), P.dy[n.name], n.channels)
                 ops.embed_bwd(P.grid, P.dy[n.name][..., :n.channels], self.grads[n.name + "/weights"])
                 P.d_embed = P.dy[n.name]
+        # bias gradients: fold the per-sample partials of every layer in one launch
+        if getattr(P, "_sum_rows_batches", None) is None:
+            P._sum_rows_batches = ops.sum_rows_batched(
+                [(P.dbpart[n.name], self.grads[n.name + "/biases"]) for n in P.convs], P.B)
+        else:
+            ops.replay_sum_rows(P._sum_rows_batches, P.B)
         if on_ready is None:
             ops.l2_add(self.params_flat[:self.n_conv_w], self.grads_flat[:self.n_conv_w], wd, P.reg, P.scratch)
         return P

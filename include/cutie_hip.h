@@ -135,6 +135,17 @@ int cutie_pack_weights(const float* w_hwio, int taps, int cin, int cout,
                        void* w_fwd, int cin_pad, void* w_dgrad, int cout_pad,
                        int dtype, cutie_stream_t stream);
 
+/* the same for up to CUTIE_MAX_BATCH layers in ONE launch (the per-step repack after Adam:
+ * main_train_json.py:156 applies the update, the next forward needs the new operands) */
+#define CUTIE_MAX_BATCH 32
+typedef struct cutie_pack_desc {
+    const float* w_hwio;
+    void* w_fwd;        /* nullable */
+    void* w_dgrad;      /* nullable */
+    int taps, cin, cout, cin_pad, cout_pad;
+} cutie_pack_desc;
+int cutie_pack_weights_batched(const cutie_pack_desc* descs, int n, int dtype, cutie_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------
  * K6  instance norm, center=False scale=False, eps 1e-6, biased variance.   Replaces
  *     tf.contrib.layers.instance_norm at model_framework.py:423 and its gradient.
@@ -159,6 +170,14 @@ int cutie_in_bwd_apply(const void* dy, int ld_dy, int dy_dtype, const void* a, i
                        int B, int HW, int C, cutie_stream_t stream);
 /* out[c] (+)= sum over b of part[b][c] */
 int cutie_sum_rows(const float* part, int B, int C, float* out, int accumulate, cutie_stream_t stream);
+/* the same for up to CUTIE_MAX_BATCH (part, out, C) triples in ONE launch: the bias gradients of
+ * every layer at the end of backward */
+typedef struct cutie_sum_rows_desc {
+    const float* part;
+    float* out;
+    int C;
+} cutie_sum_rows_desc;
+int cutie_sum_rows_batched(const cutie_sum_rows_desc* descs, int n, int B, int accumulate, cutie_stream_t stream);
 
 /* K8  Model.global_pool, model_framework.py:309-315: spatial mean broadcast back to HxW
  * (reduce_mean + nearest-neighbour resize), written into a channel slice. */

@@ -509,3 +509,40 @@ def test_batch_gather_and_convert(ops):
     dst = torch.zeros((2, 50, 32), dtype=torch.bfloat16, device=DEV)
     ops.convert(feat.to(DEV), dst)
     assert torch.equal(dst.cpu(), feat.bfloat16())
+
+
+# ------------------------------------------------------------------------------------ batched per-layer work
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+def test_batched_pack_and_sum_rows_match_single(ops, dt):
+    """One launch over a descriptor table has to write what the per-layer entry points write."""
+    from cutie_amd import capi
+    dt = capi.F32 if dt == "f32" else capi.BF16
+    g = torch.Generator().manual_seed(13)
+    shapes = [(3, 5, 128, 256), (1, 1, 256, 18), (3, 5, 40, 24), (1, 1, 1280, 256)] * 9   # > MAX_BATCH layers
+    ws = [torch.randn(s, generator=g).to(DEV) for s in shapes]
+    singles = [ops.pack_weights(w, dt) for w in ws]
+    entries = []
+    for i, (w, (wf, wd)) in enumerate(zip(ws, singles)):
+        wf2 = torch.full_like(wf, 7) if i % 3 != 1 else None          # some layers want one layout only
+        wd2 = torch.full_like(wd, 7) if i % 3 != 2 else None
+        entries.append((w, wf2, wd2))
+    batches = ops.pack_weights_batched(entries, dt)
+    assert len(batches) == 2
+    for (w, wf2, wd2), (wf, wd) in zip(entries, singles):
+        assert wf2 is None or torch.equal(wf2, wf)
+        assert wd2 is None or torch.equal(wd2, wd)
+    ws[0].mul_(2.0)                                                   # replay reads the current weights
+    ops.replay_pack(batches, dt)
+    assert torch.equal(entries[0][1], ops.pack_weights(ws[0], dt)[0])
+
+    B = 5
+    parts = [torch.randn((B, c), generator=g).to(DEV) for c in (256, 18, 24, 1000, 3)]
+    outs = [torch.randn(p.shape[1], generator=g).to(DEV) for p in parts]
+    for acc in (False, True):
+        ref = [ops.sum_rows(p, o.clone(), accumulate=acc) for p, o in zip(parts, outs)]
+        got = [o.clone() for o in outs]
+        ops.sum_rows_batched(list(zip(parts, got)), B, accumulate=acc)
+        for r, o in zip(ref, got):
+            assert torch.equal(r, o)
+    with pytest.raises(capi.CutieError):
+        ops.sum_rows_batched([(parts[0], outs[1])], B)
