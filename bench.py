@@ -104,7 +104,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=32, help="documents per GPU")
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16", "f32"])
     ap.add_argument("--rows", type=int, default=64)
     ap.add_argument("--cols", type=int, default=64)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -173,10 +173,12 @@ def main():
                           "global_batch": world * B, "parallelism": "dp%d" % world,
                           "whole_step_mfma_frac": round(docs_per_s / world * GF_PER_DOC_INBOUNDS * 1e9 / (BF16_PEAK_TFLOPS * 1e12), 4),
                           "final_total_loss": round(loss[2], 5)}}
+        if eng.loss_scale is not None:
+            out["config"]["loss_scale"], out["config"]["steps_skipped"] = eng.loss_scale_value()
         if not args.no_kernel_timing:
             ms, fl, n = timer.summary()
             ach = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
-            peak = BF16_PEAK_TFLOPS if args.dtype == "bf16" else 157.3
+            peak = BF16_PEAK_TFLOPS if args.dtype in ("bf16", "f16") else 157.3    # f16 and bf16 MFMA run at one rate
             traffic, traffic_src = None, None
             pmc = os.path.join(REPO, "profiles", "r01_d_pmc_traffic.json")
             if args.dtype == "bf16" and os.path.exists(pmc):      # PMC passes cannot run inside the timed bench

@@ -9,7 +9,7 @@ import os
 
 import torch
 
-F32, BF16 = 0, 1
+F32, BF16, F16 = 0, 1, 2
 MAX_SEGS = 6
 REDUCE_SCRATCH = 1024
 
@@ -66,9 +66,11 @@ SIGNATURES = {
     "cutie_softmax_ce_fwd": (_i, [_vp, _i, _i, _vp, _i64, _i, _vp, _vp, _vp, _vp]),
     "cutie_hnm_workspace_bytes": (_sz, [_i64]),
     "cutie_hnm_weights": (_i, [_vp, _vp, _i64, _i, _vp, _vp, _vp, _sz, _vp]),
-    "cutie_softmax_ce_bwd": (_i, [_vp, _vp, _vp, _i64, _i, _vp, _i, _i, _vp]),
-    "cutie_l2_add": (_i, [_vp, _vp, _i64, _f, _vp, _vp, _vp]),
-    "cutie_sumsq": (_i, [_vp, _i64, _i, _vp, _vp, _vp]),
+    "cutie_softmax_ce_bwd": (_i, [_vp, _vp, _vp, _i64, _i, _vp, _i, _i, _vp, _vp]),
+    "cutie_l2_add": (_i, [_vp, _vp, _i64, _f, _vp, _vp, _vp, _vp]),
+    "cutie_sumsq": (_i, [_vp, _i64, _i, _vp, _vp, _vp, _vp]),
+    "cutie_loss_scale_init": (_i, [_vp, _f, _vp]),
+    "cutie_loss_scale_update": (_i, [_vp, _vp, _f, _f, _i, _f, _f, _vp]),
     "cutie_adam_step": (_i, [_vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _vp, _f, _f, _vp]),
     "cutie_batch_gather": (_i, [_vp, _i, _i, _vp, _i, _i, _i, _vp, _i, _i, _vp]),
     "cutie_convert": (_i, [_vp, _i, _i, _vp, _i, _i, _i64, _i, _vp]),
@@ -111,11 +113,25 @@ def dt_of(t):
         return F32
     if t.dtype == torch.bfloat16:
         return BF16
+    if t.dtype == torch.float16:
+        return F16
     raise CutieError("unsupported activation dtype %s" % t.dtype)
 
 
 def torch_dtype(dt):
-    return torch.float32 if dt == F32 else torch.bfloat16
+    return {F32: torch.float32, BF16: torch.bfloat16, F16: torch.float16}[dt]
+
+
+def parse_dtype(dtype):
+    """'f32' / 'bf16' / 'f16' (or a torch dtype, or the C constant) -> C constant"""
+    table = {"f32": F32, "fp32": F32, "float32": F32, torch.float32: F32,
+             "bf16": BF16, "bfloat16": BF16, torch.bfloat16: BF16,
+             "f16": F16, "fp16": F16, "float16": F16, "half": F16, torch.float16: F16}
+    if isinstance(dtype, int) and not isinstance(dtype, bool) and dtype in (F32, BF16, F16):
+        return dtype
+    if dtype not in table:
+        raise CutieError("unknown dtype %r (f32, bf16, f16)" % (dtype,))
+    return table[dtype]
 
 
 def ptr(t):

@@ -44,14 +44,21 @@ __device__ __forceinline__ float bf2f(bf16_t b) {
     return __uint_as_float(static_cast<unsigned>(b) << 16);
 }
 
+typedef _Float16 f16_t;         // IEEE half: 11 significant bits against bf16's 8, range 6e-8 .. 65504
+typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
+typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
+
 template <int DT> struct elem;
 template <> struct elem<CUTIE_F32> { typedef float type; };
 template <> struct elem<CUTIE_BF16> { typedef bf16_t type; };
+template <> struct elem<CUTIE_F16> { typedef f16_t type; };
 
 __device__ __forceinline__ float load_as_f32(const float* p) { return *p; }
 __device__ __forceinline__ float load_as_f32(const bf16_t* p) { return bf2f(*p); }
+__device__ __forceinline__ float load_as_f32(const f16_t* p) { return static_cast<float>(*p); }
 __device__ __forceinline__ void store_from_f32(float* p, float v) { *p = v; }
 __device__ __forceinline__ void store_from_f32(bf16_t* p, float v) { *p = f2bf(v); }
+__device__ __forceinline__ void store_from_f32(f16_t* p, float v) { *p = static_cast<f16_t>(v); }   // RNE, overflow -> inf
 
 // 4 consecutive elements <-> float4 (16 B for f32, 8 B for bf16); pointers must be aligned
 __device__ __forceinline__ float4 load4(const float* p) { return *reinterpret_cast<const float4*>(p); }
@@ -64,7 +71,14 @@ __device__ __forceinline__ float4 load4(const bf16_t* p) {
     r.w = __uint_as_float(u.y & 0xffff0000u);
     return r;
 }
+__device__ __forceinline__ float4 load4(const f16_t* p) {
+    const half4_t h = *reinterpret_cast<const half4_t*>(p);
+    return make_float4((float)h.x, (float)h.y, (float)h.z, (float)h.w);
+}
 __device__ __forceinline__ void store4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+__device__ __forceinline__ void store4(f16_t* p, float4 v) {
+    *reinterpret_cast<half4_t*>(p) = half4_t{(f16_t)v.x, (f16_t)v.y, (f16_t)v.z, (f16_t)v.w};
+}
 __device__ __forceinline__ void store4(bf16_t* p, float4 v) {
     uint2 u;
     u.x = static_cast<unsigned>(f2bf(v.x)) | (static_cast<unsigned>(f2bf(v.y)) << 16);
@@ -83,6 +97,7 @@ __device__ __forceinline__ float wave_sum(float v) {
     switch (dt) {                                                        \
         case CUTIE_F32: { constexpr int NAME = CUTIE_F32; __VA_ARGS__; break; }   \
         case CUTIE_BF16: { constexpr int NAME = CUTIE_BF16; __VA_ARGS__; break; } \
+        case CUTIE_F16: { constexpr int NAME = CUTIE_F16; __VA_ARGS__; break; }   \
         default: cutie::set_error("unknown dtype %d", (int)(dt)); return CUTIE_E_ARG; \
     }
 

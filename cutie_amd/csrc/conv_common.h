@@ -31,15 +31,28 @@ struct ConvParams {
 
 template <int DT> struct Traits;
 template <> struct Traits<CUTIE_BF16> { static constexpr int ES = 2; static constexpr int BKE = 64; };
+template <> struct Traits<CUTIE_F16> { static constexpr int ES = 2; static constexpr int BKE = 64; };
 template <> struct Traits<CUTIE_F32> { static constexpr int ES = 4; static constexpr int BKE = 32; };
 
 __device__ __forceinline__ int swz(int row) { return (row >> 1) & 7; }
 
+typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
+
+// one 16x16x32 MFMA on 16-bit fragments (8 K values per lane), bf16 or f16 by the element type
+template <int DT>
+__device__ __forceinline__ float4_t mma16(short8_t a, short8_t b, float4_t c) {
+    static_assert(DT == CUTIE_BF16 || DT == CUTIE_F16, "16-bit element types only");
+    if constexpr (DT == CUTIE_BF16) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+    } else {
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8_t, a), __builtin_bit_cast(half8_t, b), c, 0, 0, 0);
+    }
+}
+
 template <int DT>
 __device__ __forceinline__ void mma_frag(const uint4& a, const uint4& b, float4_t& c) {
-    if constexpr (DT == CUTIE_BF16) {
-        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(short8_t, a), __builtin_bit_cast(short8_t, b), c,
-                                                    0, 0, 0);
+    if constexpr (DT != CUTIE_F32) {
+        c = mma16<DT>(__builtin_bit_cast(short8_t, a), __builtin_bit_cast(short8_t, b), c);
     } else {
         c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.x), __uint_as_float(b.x), c, 0, 0, 0);
         c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.y), __uint_as_float(b.y), c, 0, 0, 0);
@@ -85,8 +98,8 @@ __device__ __forceinline__ void glds16(u32x4s_t rsrc, unsigned lds_dst, unsigned
 
 }  // namespace convk
 
-// conv_wide.hip: bf16 in / bf16 out, n_out a multiple of 256, every segment cin a multiple of 64
-int launch_conv_wide(const convk::ConvParams& p, hipStream_t stream);
+// conv_wide.hip: 16-bit in / out of one type, n_out a multiple of 256, every segment cin a multiple of 64
+int launch_conv_wide(const convk::ConvParams& p, int dtype, hipStream_t stream);
 bool conv_wide_supported(const convk::ConvParams& p);
 
 }  // namespace cutie

@@ -351,7 +351,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradParams p) {
                     vd = *reinterpret_cast<const uint4*>(p.dz + off * ES);
                 }
                 int dst;
-                if constexpr (DT == CUTIE_BF16) {
+                if constexpr (ES == 2) {
                     dst = r * ROWB + (((c >> 1) ^ tr_func(r)) * 32) + (c & 1) * 16;
                 } else {
                     dst = r * ROWB + c * 16;
@@ -360,7 +360,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradParams p) {
                 *reinterpret_cast<uint4*>(Ds + dst) = vd;
             }
             __syncthreads();
-            if constexpr (DT == CUTIE_BF16) {
+            if constexpr (ES == 2) {
 #pragma unroll
                 for (int ks = 0; ks < KPIX / 32; ++ks) {
                     const int q = li >> 2, pp = li & 3;
@@ -388,7 +388,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradParams p) {
                     for (int m = 0; m < 4; ++m)
 #pragma unroll
                         for (int n = 0; n < 4; ++n)
-                            acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[m], bf[n], acc[m][n], 0, 0, 0);
+                            acc[m][n] = mma16<DT>(af[m], bf[n], acc[m][n]);
                 }
             } else {
                 for (int ks = 0; ks < KPIX / 4; ++ks) {
@@ -424,7 +424,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradParams p) {
 }
 
 // ------------------------------------------------------------------------------------------
-// bf16 weight gradient, all kw column taps of one tap row per workgroup.
+// 16-bit (bf16 / f16) weight gradient, all kw column taps of one tap row per workgroup.
 //   workgroup = 512 lanes = 8 waves as 4 (cin) x 2 (cout); tile = 128 cin x 128 cout x kw taps;
 //   a wave owns 32 cin x 64 cout for every tap: kw x 2 x 4 accumulators (160 registers at kw=5).
 //   Per image row (64 pixels of K) one input row patch [halo + 64 + halo][128 cin] and one
@@ -453,7 +453,7 @@ struct Wgrad5Params {
     int splits, mt, ntile, nwseg, pad;   // pad = halo columns staged on each side (clipped)
 };
 
-template <int KW, int MASK>
+template <int DT, int KW, int MASK>
 __global__ __launch_bounds__(WG5_NT, 2) void wgrad5_kernel(Wgrad5Params p) {
     constexpr int ES = 2;
     constexpr int ROWB = 256;       // bytes per staged pixel row: 128 channels
@@ -619,7 +619,7 @@ __global__ __launch_bounds__(WG5_NT, 2) void wgrad5_kernel(Wgrad5Params p) {
                 for (int m = 0; m < 2; ++m)
 #pragma unroll
                     for (int n = 0; n < 4; ++n)
-                        acc[t][m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[m], bf[n], acc[t][m][n], 0, 0, 0);
+                        acc[t][m][n] = mma16<DT>(af[m], bf[n], acc[t][m][n]);
             }
         }
         // switch halves by +- the stride (not XOR: a dead tap's base row may be negative)
@@ -694,12 +694,13 @@ extern "C" int cutie_conv_fwd(const cutie_conv_seg* segs, int n_segs, int B, int
     CUTIE_CHECK_ARG(segs && n_segs >= 1 && n_segs <= CUTIE_MAX_SEGS, "conv_fwd: n_segs=%d (1..%d)", n_segs, CUTIE_MAX_SEGS);
     CUTIE_CHECK_ARG(B >= 0 && H >= 1 && W >= 1 && n_out >= 1 && ld_out >= n_out, "conv_fwd: bad sizes B=%d H=%d W=%d n_out=%d ld_out=%d",
                     B, H, W, n_out, ld_out);
-    CUTIE_CHECK_ARG(dtype == CUTIE_F32 || dtype == CUTIE_BF16, "conv_fwd: dtype %d", dtype);
-    CUTIE_CHECK_ARG(out_dtype == CUTIE_F32 || out_dtype == CUTIE_BF16, "conv_fwd: out_dtype %d", out_dtype);
+    CUTIE_CHECK_ARG(dtype == CUTIE_F32 || dtype == CUTIE_BF16 || dtype == CUTIE_F16, "conv_fwd: dtype %d", dtype);
+    CUTIE_CHECK_ARG(out_dtype == CUTIE_F32 || out_dtype == dtype || (dtype == CUTIE_F32 && (out_dtype == CUTIE_BF16 || out_dtype == CUTIE_F16)),
+                    "conv_fwd: out_dtype %d must be f32 or the input dtype %d", out_dtype, dtype);
     if (B == 0) return CUTIE_OK;
     CUTIE_CHECK_ARG(out, "conv_fwd: null output");
-    const int es = dtype == CUTIE_BF16 ? 2 : 4;
-    const int bke = dtype == CUTIE_BF16 ? 64 : 32;
+    const int es = dtype == CUTIE_F32 ? 4 : 2;
+    const int bke = dtype == CUTIE_F32 ? 32 : 64;
 
     ConvParams p;
     p.nseg = n_segs;
@@ -737,7 +738,7 @@ extern "C" int cutie_conv_fwd(const cutie_conv_seg* segs, int n_segs, int B, int
     p.a_bytes = a_bytes;
     p.B = B; p.H = H; p.W = W; p.n_out = n_out;
     p.out = (char*)out; p.ld_out = ld_out; p.bias = bias; p.relu = relu; p.stats = stats;
-    const size_t oes = out_dtype == CUTIE_BF16 ? 2 : 4;
+    const size_t oes = out_dtype == CUTIE_F32 ? 4 : 2;
     size_t lds = (size_t)a_bytes + 2 * 128 * 128;
     if (lds < 256 * 128 * oes) lds = 256 * 128 * oes;
     CUTIE_CHECK_ARG(lds <= 160 * 1024, "conv_fwd: tile needs %zu B of LDS (dilation %d too large for W=%d)", lds,
@@ -745,7 +746,7 @@ extern "C" int cutie_conv_fwd(const cutie_conv_seg* segs, int n_segs, int B, int
     CUTIE_CHECK_ARG((long long)B * p.tiles_h * p.tiles_w * p.n_tiles_n < (1ll << 31), "conv_fwd: grid too large");
     // wide layers: 256-pixel x 256-channel tiles fed by LDS-DMA (conv_wide.hip)
     static const bool wide_on = !(getenv("CUTIE_CONV_WIDE") && atoi(getenv("CUTIE_CONV_WIDE")) == 0);
-    if (wide_on && dtype == CUTIE_BF16 && out_dtype == CUTIE_BF16 && cutie::conv_wide_supported(p)) {
+    if (wide_on && dtype != CUTIE_F32 && out_dtype == dtype && cutie::conv_wide_supported(p)) {
         ConvParams q = p;
         int th = 16, tcb = 1;
         while (th > 1 && th / 2 >= H && tcb * 16 < W) { th /= 2; tcb *= 2; }
@@ -753,13 +754,18 @@ extern "C" int cutie_conv_fwd(const cutie_conv_seg* segs, int n_segs, int B, int
         q.tiles_h = (int)cutie::cdiv(H, th);
         q.tiles_w = (int)cutie::cdiv(W, tcb * 16);
         q.n_tiles_n = n_out / 256;
-        if ((long long)B * q.tiles_h * q.tiles_w * q.n_tiles_n < (1ll << 31)) return cutie::launch_conv_wide(q, stream);
+        if ((long long)B * q.tiles_h * q.tiles_w * q.n_tiles_n < (1ll << 31)) return cutie::launch_conv_wide(q, dtype, stream);
     }
     if (dtype == CUTIE_BF16) {
         if (out_dtype == CUTIE_BF16) return launch_conv<CUTIE_BF16, CUTIE_BF16>(p, lds, stream);
         return launch_conv<CUTIE_BF16, CUTIE_F32>(p, lds, stream);
     }
+    if (dtype == CUTIE_F16) {
+        if (out_dtype == CUTIE_F16) return launch_conv<CUTIE_F16, CUTIE_F16>(p, lds, stream);
+        return launch_conv<CUTIE_F16, CUTIE_F32>(p, lds, stream);
+    }
     if (out_dtype == CUTIE_BF16) return launch_conv<CUTIE_F32, CUTIE_BF16>(p, lds, stream);
+    if (out_dtype == CUTIE_F16) return launch_conv<CUTIE_F32, CUTIE_F16>(p, lds, stream);
     return launch_conv<CUTIE_F32, CUTIE_F32>(p, lds, stream);
 }
 
@@ -777,8 +783,8 @@ extern "C" int cutie_conv_wgrad(const void* x, int ld_x, int cin, const void* dz
     hipStream_t stream = (hipStream_t)stream_;
     CUTIE_CHECK_ARG(B >= 0 && H >= 1 && W >= 1 && cin >= 1 && cout >= 1, "conv_wgrad: bad sizes");
     CUTIE_CHECK_ARG(kh >= 1 && kw >= 1 && (kh & 1) && (kw & 1) && dil >= 1, "conv_wgrad: kernel %dx%d dil %d", kh, kw, dil);
-    CUTIE_CHECK_ARG(dtype == CUTIE_F32 || dtype == CUTIE_BF16, "conv_wgrad: dtype %d", dtype);
-    const int es = dtype == CUTIE_BF16 ? 2 : 4;
+    CUTIE_CHECK_ARG(dtype == CUTIE_F32 || dtype == CUTIE_BF16 || dtype == CUTIE_F16, "conv_wgrad: dtype %d", dtype);
+    const int es = dtype == CUTIE_F32 ? 4 : 2;
     const int epc = 16 / es;
     CUTIE_CHECK_ARG(ld_x >= cin && ld_dz >= cout && (ld_x * es) % 16 == 0 && (ld_dz * es) % 16 == 0,
                     "conv_wgrad: rows must be 16-byte multiples (ld_x=%d ld_dz=%d)", ld_x, ld_dz);
@@ -799,7 +805,7 @@ extern "C" int cutie_conv_wgrad(const void* x, int ld_x, int cin, const void* dz
     const long long n_w = (long long)kh * kw * cin * cout;
     long long g_red = cutie::cdiv(n_w, 256);
     if (g_red > 4096) g_red = 4096;
-    if (dtype == CUTIE_BF16 && kw <= WG5_KW && (long long)B * H * W * (ld_x > ld_dz ? ld_x : ld_dz) * es < (1ll << 31)) {
+    if (dtype != CUTIE_F32 && kw <= WG5_KW && (long long)B * H * W * (ld_x > ld_dz ? ld_x : ld_dz) * es < (1ll << 31)) {
         Wgrad5Params q;
         q.x = (const char*)x; q.dz = (const char*)dz; q.ld_x = ld_x; q.cin = cin; q.ld_dz = ld_dz; q.cout = cout;
         q.B = B; q.H = H; q.W = W; q.kh = kh; q.kw = kw; q.dil = dil;
@@ -831,11 +837,16 @@ extern "C" int cutie_conv_wgrad(const void* x, int ld_x, int cin, const void* dz
                     }
             }
             const dim3 grid5(kh * q.mt * q.ntile * q.splits);
+#define CUTIE_WG5_LAUNCH_DT(DT_, KW_, MASK_)                                                                      \
+    do {                                                                                                          \
+        CUTIE_CHECK_HIP(hipFuncSetAttribute((const void*)wgrad5_kernel<DT_, KW_, MASK_>,                          \
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, WG5_LDS));                \
+        hipLaunchKernelGGL((wgrad5_kernel<DT_, KW_, MASK_>), grid5, dim3(WG5_NT), WG5_LDS, stream, q);            \
+    } while (0)
 #define CUTIE_WG5_LAUNCH(KW_, MASK_)                                                                              \
     do {                                                                                                          \
-        CUTIE_CHECK_HIP(hipFuncSetAttribute((const void*)wgrad5_kernel<KW_, MASK_>,                               \
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, WG5_LDS));                \
-        hipLaunchKernelGGL((wgrad5_kernel<KW_, MASK_>), grid5, dim3(WG5_NT), WG5_LDS, stream, q);                 \
+        if (dtype == CUTIE_BF16) CUTIE_WG5_LAUNCH_DT(CUTIE_BF16, KW_, MASK_);                                     \
+        else CUTIE_WG5_LAUNCH_DT(CUTIE_F16, KW_, MASK_);                                                          \
     } while (0)
             if (kw == 5 && mask == 0x3FF) CUTIE_WG5_LAUNCH(5, 0x3FF);
             else if (kw == 5 && mask == 0x1FE) CUTIE_WG5_LAUNCH(5, 0x1FE);
@@ -843,6 +854,7 @@ extern "C" int cutie_conv_wgrad(const void* x, int ld_x, int cin, const void* dz
             else if (kw == 3) CUTIE_WG5_LAUNCH(3, -1);
             else CUTIE_WG5_LAUNCH(1, -1);
 #undef CUTIE_WG5_LAUNCH
+#undef CUTIE_WG5_LAUNCH_DT
             CUTIE_CHECK_LAUNCH();
             hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)g_red), dim3(256), 0, stream, (const float*)workspace,
                                q.splits, n_w, dw, accumulate);
@@ -861,6 +873,8 @@ extern "C" int cutie_conv_wgrad(const void* x, int ld_x, int cin, const void* dz
     const size_t lds = (size_t)2 * 64 * 128 * es;
     if (dtype == CUTIE_BF16) {
         hipLaunchKernelGGL(wgrad_kernel<CUTIE_BF16>, grid, dim3(256), lds, stream, p);
+    } else if (dtype == CUTIE_F16) {
+        hipLaunchKernelGGL(wgrad_kernel<CUTIE_F16>, grid, dim3(256), lds, stream, p);
     } else {
         hipLaunchKernelGGL(wgrad_kernel<CUTIE_F32>, grid, dim3(256), lds, stream, p);
     }

@@ -1,4 +1,4 @@
-// K2w: forward / data-gradient convolution for the wide layers (bf16, n_out a multiple of 256),
+// K2w: forward / data-gradient convolution for the wide layers (bf16 or f16, n_out a multiple of 256),
 // built like a 256 x 256 GEMM tile with an asynchronous two-stage LDS ring.
 //
 // Same contract as conv_kernel in conv_mfma.hip (tf.nn.conv2d / atrous_conv2d + bias + ReLU of
@@ -6,7 +6,7 @@
 // how the operands reach the matrix cores:
 //   * workgroup = 512 lanes = 8 waves as 2 (pixel halves) x 4 (channel quarters); tile = 256
 //     pixels (TH rows x TWB*16 columns of one sample; 16 x 16 for the 64 x 64 grid) x 256 output
-//     channels; a wave owns 128 x 64 = 8 x 4 accumulators of v_mfma_f32_16x16x32_bf16;
+//     channels; a wave owns 128 x 64 = 8 x 4 accumulators of v_mfma_f32_16x16x32_{bf16,f16};
 //   * one K step = (tap, 64 input channels).  Its A tile (256 shifted pixels x 128 B) and B tile
 //     (256 weight rows x 128 B) go global -> LDS by `buffer_load_dwordx4 ... lds` (no registers,
 //     no ds_write): each lane's SOURCE address carries the tap shift, the XOR swizzle and the
@@ -28,6 +28,7 @@ constexpr int CW_A0 = 0, CW_B0 = 65536, CW_BUF = 32768;    // LDS map: A0 A1 B0 
 constexpr int CW_LDS = 131072;
 
 // bias, ReLU, instance-norm moments, LDS-staged coalesced store of a 256-pixel x 256-channel tile
+template <int DT>
 __device__ __forceinline__ void conv_wide_epilogue(const ConvParams& p, float4_t (&acc)[8][4], char* smem, int b, int h0,
                                                    int w0, int n0) {
     const int tid = threadIdx.x;
@@ -37,7 +38,8 @@ __device__ __forceinline__ void conv_wide_epilogue(const ConvParams& p, float4_t
     const int li = lane & 15, lg = lane >> 4;
     const int H = p.H, W = p.W, TCB = p.TWB, n_out = p.n_out;
     __syncthreads();
-    bf16_t* Cs = reinterpret_cast<bf16_t*>(smem);  // [256 pixels][256 channels]
+    typedef typename elem<DT>::type TO;
+    TO* Cs = reinterpret_cast<TO*>(smem);  // [256 pixels][256 channels]
 #pragma unroll
     for (int n = 0; n < 4; ++n) {
         const int cl = wn * 64 + n * 16 + li;
@@ -56,7 +58,7 @@ __device__ __forceinline__ void conv_wide_epilogue(const ConvParams& p, float4_t
                 if (!(h < H && w < W)) v = 0.f;
                 s1 += v;
                 s2 += v * v;
-                Cs[(mb * 16 + lg * 4 + r) * 256 + cl] = f2bf(v);
+                store_from_f32(Cs + (mb * 16 + lg * 4 + r) * 256 + cl, v);
             }
         }
         if (p.stats) {
@@ -75,12 +77,13 @@ __device__ __forceinline__ void conv_wide_epilogue(const ConvParams& p, float4_t
         const int h = h0 + mb / TCB, w = w0 + (mb % TCB) * 16 + (ml & 15);
         const int col = n0 + pc * 8;
         if (h < H && w < W && col < n_out) {
-            bf16_t* dst = reinterpret_cast<bf16_t*>(p.out) + ((long long)(b * H + h) * W + w) * p.ld_out + col;
+            TO* dst = reinterpret_cast<TO*>(p.out) + ((long long)(b * H + h) * W + w) * p.ld_out + col;
             *reinterpret_cast<uint4*>(dst) = *reinterpret_cast<const uint4*>(Cs + ml * 256 + pc * 8);
         }
     }
 }
 
+template <int DT>
 __global__ __launch_bounds__(CW_NT) void conv_wide_kernel(ConvParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -207,13 +210,13 @@ __global__ __launch_bounds__(CW_NT) void conv_wide_kernel(ConvParams p) {
                 }
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int n = 0; n < 4; ++n) mma_frag<CUTIE_BF16>(af0[m], bf0[n], acc[m][n]);
+                for (int n = 0; n < 4; ++n) mma_frag<DT>(af0[m], bf0[n], acc[m][n]);
                 __builtin_amdgcn_sched_barrier(0);
             }
 #pragma unroll
             for (int m = 0; m < 8; ++m)
 #pragma unroll
-                for (int n = 0; n < 4; ++n) mma_frag<CUTIE_BF16>(af1[m], bf1[n], acc[m][n]);
+                for (int n = 0; n < 4; ++n) mma_frag<DT>(af1[m], bf1[n], acc[m][n]);
         };
 
         // ---- software pipeline over the live (tap, channel chunk) steps of this segment
@@ -255,7 +258,7 @@ __global__ __launch_bounds__(CW_NT) void conv_wide_kernel(ConvParams p) {
         buf ^= 1;
     }
 
-    conv_wide_epilogue(p, acc, smem, b, h0, w0, n0);
+    conv_wide_epilogue<DT>(p, acc, smem, b, h0, w0, n0);
 }
 
 
@@ -269,10 +272,18 @@ bool conv_wide_supported(const ConvParams& p) {
 }
 
 // p.TH / p.TWB / tiles_* / n_tiles_n must describe 256-pixel x 256-channel tiles
-int launch_conv_wide(const ConvParams& p, hipStream_t stream) {
-    CUTIE_CHECK_HIP(hipFuncSetAttribute((const void*)conv_wide_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, CW_LDS));
+int launch_conv_wide(const ConvParams& p, int dtype, hipStream_t stream) {
     const long long grid = (long long)p.B * p.tiles_h * p.tiles_w * p.n_tiles_n;
-    hipLaunchKernelGGL(conv_wide_kernel, dim3((unsigned)grid), dim3(CW_NT), CW_LDS, stream, p);
+    if (dtype == CUTIE_BF16) {
+        CUTIE_CHECK_HIP(hipFuncSetAttribute((const void*)conv_wide_kernel<CUTIE_BF16>, hipFuncAttributeMaxDynamicSharedMemorySize, CW_LDS));
+        hipLaunchKernelGGL(conv_wide_kernel<CUTIE_BF16>, dim3((unsigned)grid), dim3(CW_NT), CW_LDS, stream, p);
+    } else if (dtype == CUTIE_F16) {
+        CUTIE_CHECK_HIP(hipFuncSetAttribute((const void*)conv_wide_kernel<CUTIE_F16>, hipFuncAttributeMaxDynamicSharedMemorySize, CW_LDS));
+        hipLaunchKernelGGL(conv_wide_kernel<CUTIE_F16>, dim3((unsigned)grid), dim3(CW_NT), CW_LDS, stream, p);
+    } else {
+        set_error("conv_wide: dtype %d", dtype);
+        return CUTIE_E_ARG;
+    }
     CUTIE_CHECK_LAUNCH();
     return CUTIE_OK;
 }

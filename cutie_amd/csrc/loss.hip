@@ -65,14 +65,16 @@ template <typename TD>
 __global__ __launch_bounds__(256) void softmax_ce_bwd_kernel(const float* __restrict__ probs,
                                                              const int32_t* __restrict__ labels,
                                                              const float* __restrict__ weight, int64_t n_cells,
-                                                             int C, TD* __restrict__ dlogits, int ld) {
+                                                             int C, TD* __restrict__ dlogits, int ld,
+                                                             const float* __restrict__ loss_scale) {
+    const float ls = loss_scale ? loss_scale[0] : 1.f;
     const int64_t total = n_cells * C;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
          i += (int64_t)gridDim.x * blockDim.x) {
         const int64_t n = i / C;
         const int c = (int)(i - n * C);
         const float w = weight[n];
-        const float g = w * (probs[i] - (labels[n] == c ? 1.f : 0.f));
+        const float g = ls * w * (probs[i] - (labels[n] == c ? 1.f : 0.f));
         store_from_f32(dlogits + n * ld + c, w == 0.f ? 0.f : g);
     }
 }
@@ -410,7 +412,8 @@ extern "C" int cutie_hnm_weights(const float* ce, const int32_t* labels, int64_t
 }
 
 extern "C" int cutie_softmax_ce_bwd(const float* probs, const int32_t* labels, const float* weight, int64_t n_cells,
-                                    int C, void* dlogits, int ld, int dtype, cutie_stream_t stream_) {
+                                    int C, void* dlogits, int ld, int dtype, const float* loss_scale,
+                                    cutie_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     CUTIE_CHECK_ARG(n_cells >= 0 && C >= 1 && ld >= C, "softmax_ce_bwd: n=%lld C=%d ld=%d", (long long)n_cells, C, ld);
     if (n_cells == 0) return CUTIE_OK;
@@ -419,7 +422,7 @@ extern "C" int cutie_softmax_ce_bwd(const float* probs, const int32_t* labels, c
     if (g > 2048) g = 2048;
     CUTIE_DISPATCH_DTYPE(dtype, DT,
         hipLaunchKernelGGL(softmax_ce_bwd_kernel<typename elem<DT>::type>, dim3((int)g), dim3(256), 0, stream, probs,
-                           labels, weight, n_cells, C, (typename elem<DT>::type*)dlogits, ld));
+                           labels, weight, n_cells, C, (typename elem<DT>::type*)dlogits, ld, loss_scale));
     CUTIE_CHECK_LAUNCH();
     return CUTIE_OK;
 }

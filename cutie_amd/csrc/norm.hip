@@ -23,6 +23,19 @@ __device__ __forceinline__ void load8(const bf16_t* p, float* v) {
     v[4] = __uint_as_float(u.z << 16); v[5] = __uint_as_float(u.z & 0xffff0000u);
     v[6] = __uint_as_float(u.w << 16); v[7] = __uint_as_float(u.w & 0xffff0000u);
 }
+__device__ __forceinline__ void load8(const f16_t* p, float* v) {
+    typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
+    const half8_t h = *reinterpret_cast<const half8_t*>(p);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = static_cast<float>(h[i]);
+}
+__device__ __forceinline__ void store8(f16_t* p, const float* v) {
+    typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
+    half8_t h;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) h[i] = static_cast<f16_t>(v[i]);
+    *reinterpret_cast<half8_t*>(p) = h;
+}
 __device__ __forceinline__ void store8(float* p, const float* v) {
     *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
     *reinterpret_cast<float4*>(p + 4) = make_float4(v[4], v[5], v[6], v[7]);

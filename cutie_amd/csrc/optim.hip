@@ -37,25 +37,50 @@ __global__ __launch_bounds__(256) void sumsq_partial_kernel(const T* __restrict_
 }
 
 __global__ __launch_bounds__(256) void l2_partial_kernel(const float* __restrict__ w, float* __restrict__ g,
-                                                         int64_t n, float wd, float* __restrict__ partials) {
+                                                         int64_t n, float wd, float* __restrict__ partials,
+                                                         const float* __restrict__ loss_scale) {
     float s = 0.f;
+    const float inv = loss_scale ? loss_scale[1] : 1.f;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)RED_BLOCKS * 256) {
         const float v = w[i];
-        g[i] += wd * v;
+        g[i] = loss_scale ? g[i] * inv + wd * v : g[i] + wd * v;
         s += v * v;
     }
     block_sum_store(s, partials + blockIdx.x);
 }
 
 __global__ __launch_bounds__(256) void final_sum_kernel(const float* __restrict__ partials, float scale,
-                                                        float* __restrict__ out) {
+                                                        float* __restrict__ out, const float* __restrict__ loss_scale) {
     float s = 0.f;
     for (int i = threadIdx.x; i < RED_BLOCKS; i += 256) s += partials[i];
     __shared__ float sh[4];
     s = wave_sum(s);
     if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
     __syncthreads();
-    if (threadIdx.x == 0) *out += scale * (sh[0] + sh[1] + sh[2] + sh[3]);
+    if (threadIdx.x == 0) {
+        const float inv = loss_scale ? loss_scale[1] : 1.f;    // the summed squares carry the scale twice
+        *out += scale * inv * inv * (sh[0] + sh[1] + sh[2] + sh[3]);
+    }
+}
+
+// dynamic loss scale, kept on the device so that no step waits for the host:
+// state = {scale, 1/scale, good steps in a row, steps skipped so far}
+__global__ void loss_scale_update_kernel(float* __restrict__ state, const float* __restrict__ gnorm_sq, float backoff,
+                                         float growth, int interval, float min_scale, float max_scale) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    float s = state[0], good = state[2];
+    const float n = *gnorm_sq;
+    if (!(fabsf(n) <= 3.0e38f)) {          // inf or NaN: the step was skipped by adam_kernel
+        s = fmaxf(s * backoff, min_scale);
+        good = 0.f;
+        state[3] += 1.f;
+    } else if (++good >= (float)interval) {
+        s = fminf(s * growth, max_scale);
+        good = 0.f;
+    }
+    state[0] = s;
+    state[1] = 1.f / s;
+    state[2] = good;
 }
 
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
@@ -63,6 +88,8 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
                                                    float b1, float b2, float eps, const float* __restrict__ gnorm_sq,
                                                    float clip, float grad_scale) {
     float scale = grad_scale;
+    // an overflowed (f16, loss-scaled) backward shows as a non-finite norm: leave p, m, v untouched
+    if (gnorm_sq && !(fabsf(*gnorm_sq) <= 3.0e38f)) return;
     if (gnorm_sq) {
         // tf.clip_by_global_norm: t * clip_norm / max(global_norm, clip_norm)
         const float norm = sqrtf(*gnorm_sq) * grad_scale;
@@ -106,13 +133,14 @@ __global__ __launch_bounds__(256) void pack_kernel(const float* __restrict__ w, 
 
 }  // namespace
 
-static int launch_final(float* partials, float scale, float* out, hipStream_t stream) {
-    hipLaunchKernelGGL(final_sum_kernel, dim3(1), dim3(256), 0, stream, partials, scale, out);
+static int launch_final(float* partials, float scale, float* out, const float* loss_scale, hipStream_t stream) {
+    hipLaunchKernelGGL(final_sum_kernel, dim3(1), dim3(256), 0, stream, partials, scale, out, loss_scale);
     CUTIE_CHECK_LAUNCH();
     return CUTIE_OK;
 }
 
-extern "C" int cutie_sumsq(const void* x, int64_t n, int dtype, float* out, float* scratch, cutie_stream_t stream_) {
+extern "C" int cutie_sumsq(const void* x, int64_t n, int dtype, float* out, float* scratch, const float* loss_scale,
+                           cutie_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     CUTIE_CHECK_ARG(n >= 0 && out && scratch, "sumsq: bad arguments");
     if (n == 0) return CUTIE_OK;
@@ -121,18 +149,40 @@ extern "C" int cutie_sumsq(const void* x, int64_t n, int dtype, float* out, floa
         hipLaunchKernelGGL(sumsq_partial_kernel<typename elem<DT>::type>, dim3(RED_BLOCKS), dim3(256), 0, stream,
                            (const typename elem<DT>::type*)x, n, scratch));
     CUTIE_CHECK_LAUNCH();
-    return launch_final(scratch, 1.f, out, stream);
+    return launch_final(scratch, 1.f, out, loss_scale, stream);
 }
 
 extern "C" int cutie_l2_add(const float* w, float* g, int64_t n, float wd, float* reg_loss, float* scratch,
-                            cutie_stream_t stream_) {
+                            const float* loss_scale, cutie_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     CUTIE_CHECK_ARG(n >= 0 && reg_loss && scratch, "l2_add: bad arguments");
     if (n == 0) return CUTIE_OK;
     CUTIE_CHECK_ARG(w && g, "l2_add: null pointer");
-    hipLaunchKernelGGL(l2_partial_kernel, dim3(RED_BLOCKS), dim3(256), 0, stream, w, g, n, wd, scratch);
+    hipLaunchKernelGGL(l2_partial_kernel, dim3(RED_BLOCKS), dim3(256), 0, stream, w, g, n, wd, scratch, loss_scale);
     CUTIE_CHECK_LAUNCH();
-    return launch_final(scratch, 0.5f * wd, reg_loss, stream);
+    return launch_final(scratch, 0.5f * wd, reg_loss, nullptr, stream);
+}
+
+extern "C" int cutie_loss_scale_init(float* state, float scale, cutie_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    CUTIE_CHECK_ARG(state && scale > 0.f && scale <= 3.0e38f, "loss_scale_init: scale %g", (double)scale);
+    const float h[4] = {scale, 1.f / scale, 0.f, 0.f};
+    CUTIE_CHECK_HIP(hipMemcpyAsync(state, h, sizeof(h), hipMemcpyHostToDevice, stream));
+    CUTIE_CHECK_HIP(hipStreamSynchronize(stream));   // h lives on this stack frame
+    return CUTIE_OK;
+}
+
+extern "C" int cutie_loss_scale_update(float* state, const float* gnorm_sq, float backoff, float growth, int interval,
+                                       float min_scale, float max_scale, cutie_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    CUTIE_CHECK_ARG(state && gnorm_sq, "loss_scale_update: null pointer");
+    CUTIE_CHECK_ARG(backoff > 0.f && backoff <= 1.f && growth >= 1.f && interval >= 1 && min_scale > 0.f && max_scale >= min_scale,
+                    "loss_scale_update: backoff %g growth %g interval %d range [%g, %g]", (double)backoff, (double)growth,
+                    interval, (double)min_scale, (double)max_scale);
+    hipLaunchKernelGGL(loss_scale_update_kernel, dim3(1), dim3(64), 0, stream, state, gnorm_sq, backoff, growth, interval,
+                       min_scale, max_scale);
+    CUTIE_CHECK_LAUNCH();
+    return CUTIE_OK;
 }
 
 extern "C" int cutie_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr_t, float beta1,

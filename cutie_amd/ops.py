@@ -14,7 +14,7 @@ IN_EPS = 1e-6  # tf.contrib.layers.instance_norm default epsilon (model_framewor
 
 
 def _bke(dt):
-    return 64 if dt == BF16 else 32
+    return 32 if dt == F32 else 64
 
 
 def pad_to(c, m):
@@ -233,18 +233,31 @@ def hnm_weights(ce, labels, ratio, weight, loss_out, workspace=None):
          ptr(workspace), workspace.numel(), stream())
 
 
-def softmax_ce_bwd(probs, labels, weight, C, dlogits):
+def softmax_ce_bwd(probs, labels, weight, C, dlogits, loss_scale=None):
     call("cutie_softmax_ce_bwd", ptr(probs), ptr(labels), ptr(weight), labels.numel(), C, ptr(dlogits),
-         ld_of(dlogits), dt_of(dlogits), stream())
+         ld_of(dlogits), dt_of(dlogits), ptr(loss_scale), stream())
 
 
 # ------------------------------------------------------------------------------------ K12, K14
-def l2_add(w, g, wd, reg_loss, scratch):
-    call("cutie_l2_add", ptr(w), ptr(g), w.numel(), float(wd), ptr(reg_loss), ptr(scratch), stream())
+def l2_add(w, g, wd, reg_loss, scratch, loss_scale=None):
+    """g = g / S + wd * w  (S = 1 without loss_scale);  reg_loss += wd * sum(w^2) / 2"""
+    call("cutie_l2_add", ptr(w), ptr(g), w.numel(), float(wd), ptr(reg_loss), ptr(scratch), ptr(loss_scale), stream())
 
 
-def sumsq(x, out, scratch):
-    call("cutie_sumsq", ptr(x), x.numel(), dt_of(x), ptr(out), ptr(scratch), stream())
+def sumsq(x, out, scratch, loss_scale=None):
+    call("cutie_sumsq", ptr(x), x.numel(), dt_of(x), ptr(out), ptr(scratch), ptr(loss_scale), stream())
+
+
+def loss_scale_state(scale, device):
+    """device array {S, 1/S, good steps in a row, steps skipped} (include/cutie_hip.h, K12)"""
+    state = torch.zeros(4, dtype=torch.float32, device=device)
+    call("cutie_loss_scale_init", ptr(state), float(scale), stream())
+    return state
+
+
+def loss_scale_update(state, gnorm_sq, backoff=0.5, growth=2.0, interval=1000, min_scale=1.0, max_scale=65536.0):
+    call("cutie_loss_scale_update", ptr(state), ptr(gnorm_sq), float(backoff), float(growth), int(interval),
+         float(min_scale), float(max_scale), stream())
 
 
 def adam_step(p, g, m, v, lr_t, beta1, beta2, eps, gnorm_sq, clip, grad_scale=1.0):

@@ -19,7 +19,8 @@ from .parallel import GradBuckets, dist_info
 
 class Trainer(object):
     def __init__(self, engine, learning_rate=1e-4, clip_norm=10.0, beta1=0.9, beta2=0.999, epsilon=1e-8,
-                 lr_decay_step=13000, lr_decay_factor=0.1, n_buckets=4, check_inputs=False):
+                 lr_decay_step=13000, lr_decay_factor=0.1, n_buckets=4, check_inputs=False,
+                 scale_growth_interval=1000):
         self.eng = engine
         self.lr = float(learning_rate)
         self.clip, self.b1, self.b2, self.eps = float(clip_norm), beta1, beta2, epsilon
@@ -27,6 +28,7 @@ class Trainer(object):
         self.iter = 0          # the reference's `iter` (drives lr decay)
         self.t = 0             # Adam's step count
         self.check_inputs = check_inputs
+        self.scale_growth_interval = int(scale_growth_interval)
         self.m = torch.zeros_like(engine.params_flat)
         self.v = torch.zeros_like(engine.params_flat)
         self.rank, self.world = dist_info()
@@ -53,6 +55,10 @@ class Trainer(object):
         lr_t = self.lr * math.sqrt(1.0 - self.b2 ** self.t) / (1.0 - self.b1 ** self.t)
         ops.adam_step(eng.params_flat, eng.grads_flat, self.m, self.v, lr_t, self.b1, self.b2, self.eps, gn,
                       self.clip, grad_scale=1.0 / self.world)
+        if eng.loss_scale is not None:
+            # f16: an overflowed backward made gn non-finite and Adam left everything untouched; halve
+            # the scale then, double it after a run of good steps - on the device, nobody waits
+            ops.loss_scale_update(eng.loss_scale, gn, interval=self.scale_growth_interval)
         eng.repack()
         self.iter += 1
         if not fetch:

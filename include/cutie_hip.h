@@ -15,7 +15,7 @@
  *   - activations are NHWC with an explicit leading dimension: element (b,h,w,c) of a view
  *     lives at base[((b*H + h)*W + w)*ld + c]; a concat is a wider buffer whose producers
  *     write channel slices (model_framework.py:294-296 needs no kernel).
- *   - dtype: CUTIE_F32 or CUTIE_BF16 activations; statistics, losses, parameters and
+ *   - dtype: CUTIE_F32, CUTIE_BF16 or CUTIE_F16 activations; statistics, losses, parameters and
  *     gradients are always f32; ids/labels are int32 (labels in the grid are int8).
  */
 #ifndef CUTIE_HIP_H
@@ -30,6 +30,7 @@ extern "C" {
 
 #define CUTIE_F32 0
 #define CUTIE_BF16 1
+#define CUTIE_F16 2  /* IEEE half activations; training uses the loss scale of K12 below */
 
 #define CUTIE_OK 0
 #define CUTIE_E_ARG (-1)      /* bad shape / pointer / alignment / unsupported option */
@@ -206,7 +207,7 @@ int cutie_hnm_weights(const float* ce, const int32_t* labels, int64_t n_cells, i
                       cutie_stream_t stream);
 int cutie_softmax_ce_bwd(const float* probs, const int32_t* labels, const float* weight,
                          int64_t n_cells, int C, void* dlogits, int ld, int dtype,
-                         cutie_stream_t stream);
+                         const float* loss_scale /* nullable, see K12 */, cutie_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------
  * K12,K14  L2 regulariser, global-norm clip and Adam over flat f32 buffers.   Replaces
@@ -219,12 +220,26 @@ int cutie_softmax_ce_bwd(const float* probs, const int32_t* labels, const float*
  * adam:  scale = clip / max(sqrt(*gnorm_sq), clip);  g' = g*scale;
  *        m = b1*m + (1-b1)*g';  v = b2*v + (1-b2)*g'^2;  p -= lr_t * m / (sqrt(v) + eps)
  *        with lr_t = lr*sqrt(1-b2^t)/(1-b1^t) computed by the caller (TF's form).
+ *        A non-finite *gnorm_sq leaves p, m and v untouched (the step is skipped).
+ *
+ * Loss scale (no counterpart in the reference, which trains in f32; it is what lets the CUTIE_F16
+ * path keep the gradients the reference computes instead of flushing them to zero): a device
+ * array `loss_scale` = {S, 1/S, good steps in a row, steps skipped}.  cutie_softmax_ce_bwd
+ * multiplies dlogits by S, so every activation gradient, weight gradient and bias gradient of the
+ * backward pass carries S; cutie_l2_add (g = g/S + wd*w) and cutie_sumsq (sum/S^2) take it out
+ * again when they are handed the same array.  NULL means S = 1 everywhere.
+ * cutie_loss_scale_update, after the Adam step: a non-finite *gnorm_sq multiplies S by `backoff`
+ * (>= min_scale), `interval` finite steps in a row multiply it by `growth` (<= max_scale).  All of
+ * it stays on the device: no step waits for the host.
  */
 #define CUTIE_REDUCE_SCRATCH 1024 /* floats of caller scratch for the two-stage reductions */
 int cutie_l2_add(const float* w, float* g, int64_t n, float wd, float* reg_loss, float* scratch,
-                 cutie_stream_t stream);
+                 const float* loss_scale /* nullable */, cutie_stream_t stream);
 int cutie_sumsq(const void* x, int64_t n, int dtype, float* out, float* scratch,
-                cutie_stream_t stream);
+                const float* loss_scale /* nullable */, cutie_stream_t stream);
+int cutie_loss_scale_init(float* state /* device, 4 floats */, float scale, cutie_stream_t stream);
+int cutie_loss_scale_update(float* state, const float* gnorm_sq, float backoff, float growth,
+                            int interval, float min_scale, float max_scale, cutie_stream_t stream);
 int cutie_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr_t,
                     float beta1, float beta2, float eps, const float* gnorm_sq, float clip,
                     float grad_scale, cutie_stream_t stream);
@@ -234,7 +249,7 @@ int cutie_adam_step(float* p, const float* g, float* m, float* v, int64_t n, flo
 int cutie_batch_gather(const void* feat, int ld_feat, int n_src, const int32_t* idx, int n_cells,
                        int B, int C, void* out, int ld_out, int dtype, cutie_stream_t stream);
 
-/* dtype conversion of a [n_rows, C] view (used for the image input and f32 <-> bf16 views) */
+/* dtype conversion of a [n_rows, C] view (used for the image input and f32 <-> bf16 / f16 views) */
 int cutie_convert(const void* src, int ld_src, int src_dtype, void* dst, int ld_dst,
                   int dst_dtype, int64_t n_rows, int C, cutie_stream_t stream);
 

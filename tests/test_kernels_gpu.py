@@ -18,6 +18,8 @@ from oracle import cutie_oracle as co  # noqa: E402
 from oracle import grid_oracle as go  # noqa: E402
 
 DEV = "cuda:0"
+TDT = {"f32": torch.float32, "bf16": torch.bfloat16, "f16": torch.float16}
+CDT = {"f32": 0, "bf16": 1, "f16": 2}     # include/cutie_hip.h CUTIE_F32 / CUTIE_BF16 / CUTIE_F16
 
 
 @pytest.fixture(scope="module")
@@ -115,11 +117,11 @@ def test_grid_build_edges(ops):
 
 
 # ------------------------------------------------------------------------------------ K1
-@pytest.mark.parametrize("dt", ["f32", "bf16"])
+@pytest.mark.parametrize("dt", ["f32", "bf16", "f16"])
 def test_embed_fwd_bwd(ops, dt):
     g = torch.Generator().manual_seed(1)
     V, E, n = 300, 128, 5000
-    tdt = torch.float32 if dt == "f32" else torch.bfloat16
+    tdt = TDT[dt]
     table = torch.rand((V, E), generator=g) * 2 - 1
     ids = torch.randint(0, V, (n,), generator=g, dtype=torch.int32)
     ids[torch.rand(n, generator=g) < 0.6] = 0
@@ -137,7 +139,7 @@ def test_embed_fwd_bwd(ops, dt):
     if dt == "f32":
         assert torch.equal(got, ref)
     else:
-        assert torch.equal(got, ref.bfloat16().float())
+        assert torch.equal(got, ref.to(tdt).float())
     assert torch.all(out[:, E:] == 7.0)
     # backward: scatter-add
     dout = (torch.randn((n, E), generator=g)).to(tdt)
@@ -169,14 +171,14 @@ CONV_CASES = [
 ]
 
 
-@pytest.mark.parametrize("dt", ["f32", "bf16"])
+@pytest.mark.parametrize("dt", ["f32", "bf16", "f16"])
 @pytest.mark.parametrize("case", CONV_CASES)
 def test_conv_fwd(ops, dt, case):
     from cutie_amd import capi
     B, H, W, cin, cout, kh, kw, dil = case
     g = torch.Generator().manual_seed(hash(case) % 1000)
-    tdt = torch.float32 if dt == "f32" else torch.bfloat16
-    cdt = capi.F32 if dt == "f32" else capi.BF16
+    tdt = TDT[dt]
+    cdt = CDT[dt]
     x = _rand_act(g, (B, H, W, cin), tdt)
     w = (torch.randn((kh, kw, cin, cout), generator=g) * 0.05).to(tdt).float()
     bias = torch.randn(cout, generator=g) * 0.1
@@ -198,20 +200,20 @@ def test_conv_fwd(ops, dt, case):
     assert relerr(stats, ref_s) < (1e-4 if dt == "f32" else 2e-3)
 
 
-@pytest.mark.parametrize("dt", ["f32", "bf16"])
+@pytest.mark.parametrize("dt", ["f32", "bf16", "f16"])
 def test_conv_bf16_out_and_no_relu(ops, dt):
     from cutie_amd import capi
     B, H, W, cin, cout, kh, kw, dil = 1, 16, 64, 64, 128, 3, 5, 2
     g = torch.Generator().manual_seed(5)
-    tdt = torch.float32 if dt == "f32" else torch.bfloat16
-    cdt = capi.F32 if dt == "f32" else capi.BF16
+    tdt = TDT[dt]
+    cdt = CDT[dt]
     x = _rand_act(g, (B, H, W, cin), tdt)
     w = (torch.randn((kh, kw, cin, cout), generator=g) * 0.05).to(tdt).float()
     ref = co.conv_raw(x.double(), w.double(), dil)
     wf, _ = ops.pack_weights(w.to(DEV), cdt)
-    out = torch.zeros((B, H, W, cout), dtype=torch.bfloat16, device=DEV)
+    out = torch.zeros((B, H, W, cout), dtype=torch.float16 if dt == "f16" else torch.bfloat16, device=DEV)
     ops.conv_fwd([dict(x=x.to(DEV), w=wf, cin=cin, kh=kh, kw=kw, dil=dil)], out, cout)
-    assert relerr(out, ref) < 6e-3     # one bf16 rounding of the output
+    assert relerr(out, ref) < (8e-4 if dt == "f16" else 6e-3)     # one 16-bit rounding of the output
 
 
 WIDE_CASES = [
@@ -226,66 +228,68 @@ WIDE_CASES = [
 ]
 
 
+@pytest.mark.parametrize("dt", ["bf16", "f16"])
 @pytest.mark.parametrize("case", WIDE_CASES)
-def test_conv_wide_bf16(ops, case):
-    from cutie_amd import capi
+def test_conv_wide_16bit(ops, case, dt):
     B, H, W, cin, cout, kh, kw, dil = case
     g = torch.Generator().manual_seed(hash(case) % 1000 + 7)
-    x = _rand_act(g, (B, H, W, cin), torch.bfloat16)
-    w = (torch.randn((kh, kw, cin, cout), generator=g) * 0.05).bfloat16().float()
+    tdt = TDT[dt]
+    x = _rand_act(g, (B, H, W, cin), tdt)
+    w = (torch.randn((kh, kw, cin, cout), generator=g) * 0.05).to(tdt).float()
     bias = torch.randn(cout, generator=g) * 0.1
     ref_a = torch.relu(co.conv_raw(x.double(), w.double(), dil) + bias.double())
-    wf, _ = ops.pack_weights(w.to(DEV), capi.BF16)
+    wf, _ = ops.pack_weights(w.to(DEV), CDT[dt])
     ld_out = cout + 8
-    out = torch.full((B, H, W, ld_out), 3.0, dtype=torch.bfloat16, device=DEV)
+    out = torch.full((B, H, W, ld_out), 3.0, dtype=tdt, device=DEV)
     stats = torch.zeros((B, cout, 2), dtype=torch.float32, device=DEV)
-    xd = torch.zeros((B, H, W, cin + 64), dtype=torch.bfloat16, device=DEV)
+    xd = torch.zeros((B, H, W, cin + 64), dtype=tdt, device=DEV)
     xd[..., 32:32 + cin] = x.to(DEV)
     ops.conv_fwd([dict(x=xd[..., 32:32 + cin], w=wf, cin=cin, kh=kh, kw=kw, dil=dil)], out[..., :cout], cout,
                  bias=bias.to(DEV), relu=True, stats=stats)
     torch.cuda.synchronize()
-    assert relerr(out[..., :cout], ref_a) < 6e-3            # one bf16 rounding of the output
-    # against the bf16-rounded reference the only differences are last-bit rounding flips
-    assert (out[..., :cout].float().cpu() - ref_a.float().bfloat16().float()).abs().max() < 0.07
+    assert relerr(out[..., :cout], ref_a) < (8e-4 if dt == "f16" else 6e-3)            # one rounding of the output
+    # against the rounded reference the only differences are last-bit rounding flips
+    assert (out[..., :cout].float().cpu() - ref_a.float().to(tdt).float()).abs().max() < (0.009 if dt == "f16" else 0.07)
     assert torch.all(out[..., cout:] == 3.0)
     ref_s = torch.stack([ref_a.sum(dim=(1, 2)), (ref_a ** 2).sum(dim=(1, 2))], dim=-1)
     assert relerr(stats, ref_s) < 2e-3
 
 
-def test_conv_wide_dgrad_multi_segment(ops):
+@pytest.mark.parametrize("dt", ["bf16", "f16"])
+def test_conv_wide_dgrad_multi_segment(ops, dt):
     """data gradient of a 256-channel tensor consumed by a 3x5 dil 4 conv (256 outputs), a 3x5
     dil 16 conv (256 outputs) and channels [256:512) of a 1x1 conv over a 768-channel concat."""
-    from cutie_amd import capi
+    tdt = TDT[dt]
     g = torch.Generator().manual_seed(19)
     B, H, W, C = 1, 32, 64, 256
-    w1 = (torch.randn((3, 5, C, 256), generator=g) * 0.03).bfloat16().float()
-    w2 = (torch.randn((3, 5, C, 256), generator=g) * 0.03).bfloat16().float()
-    w3 = (torch.randn((1, 1, 768, 128), generator=g) * 0.03).bfloat16().float()
-    dz1 = _rand_act(g, (B, H, W, 256), torch.bfloat16)
-    dz2 = _rand_act(g, (B, H, W, 256), torch.bfloat16)
-    dz3 = _rand_act(g, (B, H, W, 128), torch.bfloat16)
+    w1 = (torch.randn((3, 5, C, 256), generator=g) * 0.03).to(tdt).float()
+    w2 = (torch.randn((3, 5, C, 256), generator=g) * 0.03).to(tdt).float()
+    w3 = (torch.randn((1, 1, 768, 128), generator=g) * 0.03).to(tdt).float()
+    dz1 = _rand_act(g, (B, H, W, 256), tdt)
+    dz2 = _rand_act(g, (B, H, W, 256), tdt)
+    dz3 = _rand_act(g, (B, H, W, 128), tdt)
     x = torch.zeros((B, H, W, C), dtype=torch.float64, requires_grad=True)
     z = torch.zeros((B, H, W, 256), dtype=torch.float64)
     y1 = co.conv_raw(x, w1.double(), 4)
     y2 = co.conv_raw(x, w2.double(), 16)
     y3 = co.conv_raw(torch.cat([z, x, z], dim=3), w3.double(), 1)
     ((y1 * dz1.double()).sum() + (y2 * dz2.double()).sum() + (y3 * dz3.double()).sum()).backward()
-    wd = [ops.pack_weights(w.to(DEV), capi.BF16, want_fwd=False)[1] for w in (w1, w2, w3)]
-    out = torch.zeros((B, H, W, C), dtype=torch.bfloat16, device=DEV)
+    wd = [ops.pack_weights(w.to(DEV), CDT[dt], want_fwd=False)[1] for w in (w1, w2, w3)]
+    out = torch.zeros((B, H, W, C), dtype=tdt, device=DEV)
     ops.conv_fwd([dict(x=dz1.to(DEV), w=wd[0], cin=256, kh=3, kw=5, dil=4, flip=True),
                   dict(x=dz2.to(DEV), w=wd[1], cin=256, kh=3, kw=5, dil=16, flip=True),
                   dict(x=dz3.to(DEV), w=wd[2], cin=128, kh=1, kw=1, dil=1, flip=True, n_off=256)], out, C)
-    assert relerr(out, x.grad) < 6e-3
+    assert relerr(out, x.grad) < (8e-4 if dt == "f16" else 6e-3)
 
 
-@pytest.mark.parametrize("dt", ["f32", "bf16"])
+@pytest.mark.parametrize("dt", ["f32", "bf16", "f16"])
 def test_conv_dgrad_multi_segment(ops, dt):
     """d(loss)/dx of a tensor consumed by two convs (3x5 dil 2 with 128 outputs, and channels
     [0:64) of a 3x5 dil 1 conv over a 128-channel concat with 64 outputs) in ONE launch."""
     from cutie_amd import capi
     g = torch.Generator().manual_seed(9)
-    tdt = torch.float32 if dt == "f32" else torch.bfloat16
-    cdt = capi.F32 if dt == "f32" else capi.BF16
+    tdt = TDT[dt]
+    cdt = CDT[dt]
     B, H, W, C = 2, 12, 64, 64
     w1 = (torch.randn((3, 5, C, 128), generator=g) * 0.05).to(tdt).float()
     w2 = (torch.randn((3, 5, 128, 64), generator=g) * 0.05).to(tdt).float()
@@ -315,12 +319,12 @@ WGRAD_CASES = [
 ]
 
 
-@pytest.mark.parametrize("dt", ["f32", "bf16"])
+@pytest.mark.parametrize("dt", ["f32", "bf16", "f16"])
 @pytest.mark.parametrize("case", WGRAD_CASES)
 def test_conv_wgrad(ops, dt, case):
     B, H, W, cin, cout, kh, kw, dil = case
     g = torch.Generator().manual_seed(hash(case) % 1000 + 1)
-    tdt = torch.float32 if dt == "f32" else torch.bfloat16
+    tdt = TDT[dt]
     x = _rand_act(g, (B, H, W, cin), tdt)
     dz = _rand_act(g, (B, H, W, cout), tdt)
     w = torch.zeros((kh, kw, cin, cout), dtype=torch.float64, requires_grad=True)
@@ -337,11 +341,11 @@ def test_conv_wgrad(ops, dt, case):
 
 
 # ------------------------------------------------------------------------------------ K6, K8
-@pytest.mark.parametrize("dt", ["f32", "bf16"])
+@pytest.mark.parametrize("dt", ["f32", "bf16", "f16"])
 @pytest.mark.parametrize("C", [256, 64, 18])
 def test_instance_norm_fwd_bwd(ops, dt, C):
     g = torch.Generator().manual_seed(3)
-    tdt = torch.float32 if dt == "f32" else torch.bfloat16
+    tdt = TDT[dt]
     B, H, W = 2, 20, 24
     a = torch.relu(torch.randn((B, H, W, C), generator=g) + 0.3).to(tdt)
     a[0, :, :, 1] = 0     # all-zero channel -> y = 0
@@ -512,11 +516,10 @@ def test_batch_gather_and_convert(ops):
 
 
 # ------------------------------------------------------------------------------------ batched per-layer work
-@pytest.mark.parametrize("dt", ["f32", "bf16"])
+@pytest.mark.parametrize("dt", ["f32", "bf16", "f16"])
 def test_batched_pack_and_sum_rows_match_single(ops, dt):
     """One launch over a descriptor table has to write what the per-layer entry points write."""
-    from cutie_amd import capi
-    dt = capi.F32 if dt == "f32" else capi.BF16
+    dt = CDT[dt]
     g = torch.Generator().manual_seed(13)
     shapes = [(3, 5, 128, 256), (1, 1, 256, 18), (3, 5, 40, 24), (1, 1, 1280, 256)] * 9   # > MAX_BATCH layers
     ws = [torch.randn(s, generator=g).to(DEV) for s in shapes]
@@ -544,5 +547,97 @@ def test_batched_pack_and_sum_rows_match_single(ops, dt):
         ops.sum_rows_batched(list(zip(parts, got)), B, accumulate=acc)
         for r, o in zip(ref, got):
             assert torch.equal(r, o)
-    with pytest.raises(capi.CutieError):
+    from cutie_amd.capi import CutieError
+    with pytest.raises(CutieError):
         ops.sum_rows_batched([(parts[0], outs[1])], B)
+
+
+# ------------------------------------------------------------------------------------ loss scale (f16 training)
+def test_loss_scale_state_machine(ops):
+    """softmax_ce_bwd puts S on the gradients, l2_add / sumsq take it out, a non-finite norm skips
+    the Adam step and halves S, a run of finite steps doubles it - all without a host round trip."""
+    g = torch.Generator().manual_seed(21)
+    ls = ops.loss_scale_state(1024.0, DEV)
+    assert ls.cpu().tolist() == [1024.0, 1.0 / 1024.0, 0.0, 0.0]
+    n, C = 1000, 18
+    probs = torch.softmax(torch.randn((n, C), generator=g), dim=-1).to(DEV)
+    labels = torch.randint(0, C, (n,), generator=g, dtype=torch.int32).to(DEV)
+    weight = (torch.rand(n, generator=g) * (torch.rand(n, generator=g) < 0.5)).to(DEV) * 1e-3
+    d1 = torch.zeros((n, C), dtype=torch.float32, device=DEV)
+    dS = torch.zeros((n, C), dtype=torch.float16, device=DEV)
+    ops.softmax_ce_bwd(probs, labels, weight, C, d1)
+    ops.softmax_ce_bwd(probs, labels, weight, C, dS, ls)
+    assert relerr(dS.float() / 1024.0, d1.double()) < 6e-4          # one f16 rounding; unscaled it would lose the small ones
+    # l2_add: g/S + wd*w, sumsq: sum/S^2
+    w = torch.randn(5000, generator=g).to(DEV)
+    gr = (torch.randn(5000, generator=g) * 300).to(DEV)
+    scratch = torch.zeros(1024, dtype=torch.float32, device=DEV)
+    reg = torch.zeros(1, dtype=torch.float32, device=DEV)
+    g2 = gr.clone()
+    ops.l2_add(w, g2, 5e-4, reg, scratch, ls)
+    assert relerr(g2, gr.double() / 1024.0 + 5e-4 * w.double()) < 1e-6
+    assert abs(float(reg) - 2.5e-4 * float((w.double() ** 2).sum())) < 1e-5 * float(reg)
+    nsq = torch.zeros(1, dtype=torch.float32, device=DEV)
+    ops.sumsq(gr.half(), nsq, scratch, ls)
+    assert abs(float(nsq) - float((gr.half().double() ** 2).sum()) / 1024.0 ** 2) < 1e-5 * float(nsq)
+    # Adam: finite norm -> update; non-finite -> nothing moves
+    p, m, v = w.clone(), torch.zeros_like(w), torch.zeros_like(w)
+    ops.adam_step(p, g2, m, v, 1e-3, 0.9, 0.999, 1e-8, nsq, 10.0)
+    assert not torch.equal(p, w)
+    for bad in (float("inf"), float("nan")):
+        p2, m2, v2 = p.clone(), m.clone(), v.clone()
+        nbad = torch.full((1,), bad, dtype=torch.float32, device=DEV)
+        ops.adam_step(p2, g2, m2, v2, 1e-3, 0.9, 0.999, 1e-8, nbad, 10.0)
+        assert torch.equal(p2, p) and torch.equal(m2, m) and torch.equal(v2, v)
+    # the scale itself
+    ninf = torch.full((1,), float("inf"), dtype=torch.float32, device=DEV)
+    ops.loss_scale_update(ls, ninf, interval=3)
+    assert ls.cpu().tolist() == [512.0, 1.0 / 512.0, 0.0, 1.0]
+    for k in range(3):
+        ops.loss_scale_update(ls, nsq, interval=3)
+    assert ls.cpu().tolist() == [1024.0, 1.0 / 1024.0, 0.0, 1.0]
+    ops.loss_scale_update(ls, nsq, interval=3)
+    assert ls.cpu().tolist()[2] == 1.0
+    for k in range(40):                                              # clamps at both ends
+        ops.loss_scale_update(ls, ninf, interval=3, min_scale=1.0)
+    assert ls.cpu().tolist()[0] == 1.0
+    for k in range(40 * 3):
+        ops.loss_scale_update(ls, nsq, interval=3, max_scale=65536.0)
+    assert ls.cpu().tolist()[0] == 65536.0
+
+
+def test_f16_training_recovers_from_overflow():
+    """An absurd initial scale overflows the first backward passes: those steps must leave the
+    parameters untouched, the scale must come down by itself, and training must then proceed."""
+    import types
+    from cutie_amd.model_cutie_aspp import CUTIERes
+    from cutie_amd.runtime import Engine
+    from cutie_amd.train import Trainer
+    V, E, C, H, W, B = 300, 128, 18, 32, 32, 2
+    g = torch.Generator().manual_seed(5)
+    grid = torch.zeros((B, H, W), dtype=torch.int32)
+    occ = torch.rand((B, H, W), generator=g) < 0.15
+    grid[occ] = torch.randint(1, V, (int(occ.sum()),), generator=g, dtype=torch.int32)
+    labels = torch.zeros((B, H, W), dtype=torch.int32)
+    fg = occ & (torch.rand((B, H, W), generator=g) < 0.3)
+    labels[fg] = torch.randint(1, C, (int(fg.sum()),), generator=g, dtype=torch.int32)
+    p = types.SimpleNamespace(embedding_size=E, weight_decay=5e-4, hard_negative_ratio=3, batch_size=B)
+    net = CUTIERes(V, C, p)
+    net.build_loss()
+    eng = Engine(net, DEV, dtype="f16", seed=0, loss_scale=2.0 ** 40)
+    tr = Trainer(eng, learning_rate=1e-3)
+    before = eng.params_flat.clone()
+    out = tr.step({"grid_table": grid, "gt_classes": labels})
+    assert not np.isfinite(out["global_norm"])
+    assert torch.equal(eng.params_flat, before)                      # skipped
+    S, skipped = eng.loss_scale_value()
+    assert S == 2.0 ** 39 and skipped == 1
+    losses = []
+    for k in range(60):
+        out = tr.step({"grid_table": grid, "gt_classes": labels})
+        losses.append(out["total_loss"])
+    S, skipped = eng.loss_scale_value()
+    print("scale settled at 2^%d after %d skipped steps; loss %.4f -> %.4f" % (int(np.log2(S)), skipped, losses[0], losses[-1]))
+    assert 1 < skipped < 40 and np.isfinite(out["global_norm"])
+    assert not torch.equal(eng.params_flat, before)
+    assert np.isfinite(losses[-1]) and losses[-1] < losses[0]

@@ -61,7 +61,7 @@ def oracle_run():
     return dict(B=B, H=H, W=W, grid=grid, labels=labels, params=params, out=out)
 
 
-@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("dtype", ["f32", "bf16", "f16"])
 def test_cutie_aspp_forward_backward_parity(oracle_run, dtype):
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
@@ -69,7 +69,7 @@ def test_cutie_aspp_forward_backward_parity(oracle_run, dtype):
     from cutie_amd.runtime import Engine
     from cutie_amd.train import Trainer
     r = oracle_run
-    tol = 1e-4 if dtype == "f32" else 6e-2
+    tol = {"f32": 1e-4, "bf16": 6e-2, "f16": 2e-2}[dtype]
     net = CUTIERes(V, C, params_ns())
     fetches = net.build_loss()
     assert [f.name for f in fetches] == ["model_loss", "regularization_loss", "total_loss", "cls_logits", "softmax"]
@@ -83,12 +83,14 @@ def test_cutie_aspp_forward_backward_parity(oracle_run, dtype):
                  "decoder1_1", "cls_logits", "softmax"):
         report[name] = rel(eng.get(P, name), L[name])
     print(dtype, "layer errors", {k: "%.2e" % v for k, v in report.items()})
-    assert report["embedding"] <= (1e-7 if dtype == "f32" else 4e-3)   # f64 -> f32 / bf16 rounding of the table
+    assert report["embedding"] <= {"f32": 1e-7, "bf16": 4e-3, "f16": 5e-4}[dtype]   # rounding of the table
     report2 = {name: rel2(eng.get(P, name), L[name])[0] for name in report}
     print(dtype, "layer rel-L2 errors", {k: "%.2e" % v for k, v in report2.items()})
     for name, e in report.items():
         if dtype == "f32":
             assert e < tol, (name, e)
+        elif dtype == "f16":      # the north-star 16-bit bound, in both norms
+            assert report2[name] < 2e-2 and e < 2e-2, (name, report2[name], e)
         else:
             assert report2[name] < 6e-2 and e < 8e-2, (name, report2[name], e)
     # aspp_4 is the spatial mean of an instance-normalised tensor: ~0 on both sides
@@ -108,6 +110,8 @@ def test_cutie_aspp_forward_backward_parity(oracle_run, dtype):
     assert agree_decided >= 0.999
     if dtype == "f32":
         assert agree >= 0.999
+    S = eng.loss_scale_value()[0]
+    assert (S > 1.0) == (dtype == "f16")
     # loss + backward.  Gradients are compared on the device's own ReLU activation pattern (see
     # oracle cbrn(mask=...)); how many cells sit on the other side of a kink in f64 is reported.
     eng.loss_backward(P)
@@ -125,7 +129,7 @@ def test_cutie_aspp_forward_backward_parity(oracle_run, dtype):
                                  r["labels"], 3)
     sel_diff = int(((P.weight.cpu() != 0) != (w_ref != 0)).sum())
     print(dtype, "hard-negative selection: cells that differ from the oracle's:", sel_diff)
-    derr = {k: rel(P.dy[k][..., :g.shape[-1]], g) for k, g in o["dlayers"].items() if k in P.dy and k != "encoder1_8"}
+    derr = {k: rel(P.dy[k][..., :g.shape[-1]].double() / S, g) for k, g in o["dlayers"].items() if k in P.dy and k != "encoder1_8"}
     print(dtype, "d(layer) errors", {k: "%.2e" % v for k, v in derr.items()})
     gerr = {k: rel(eng.grads[k], g) for k, g in o["grads"].items()}
     gerr["aspp_1x1/weights"] = rel(eng.grads["aspp_1x1/weights"][:, :, :768], o["grads"]["aspp_1x1/weights"][:, :, :768])
@@ -136,12 +140,15 @@ def test_cutie_aspp_forward_backward_parity(oracle_run, dtype):
         assert sel_diff == 0
         for k, e in list(derr.items()) + list(gerr.items()):
             assert e < 1e-3, (k, e)
+    elif dtype == "f16":   # gradients come out of the loss scale again; measured ~5e-3
+        for k, e in g2.items():
+            assert e < 3e-2, (k, e)
     else:   # bf16: measured ~2e-2..6e-2 rel-L2 (activations carry ~3e-2 by the last layers)
         for k, e in g2.items():
             assert e < 1.5e-1, (k, e)
     gn = math_sqrt(eng.global_norm_sq(P, tf_indexed_slices=True))
     gn_ref = float(co.global_norm_tf(o["grads"], o["d_embedding_out"]))
-    assert abs(gn - gn_ref) < (1e-3 if dtype == "f32" else 1e-1) * gn_ref
+    assert abs(gn - gn_ref) < {"f32": 1e-3, "bf16": 1e-1, "f16": 2e-2}[dtype] * gn_ref
     # one Adam step through the Trainer == oracle step
     eng.load_params(r["params"])
     tr = Trainer(eng, learning_rate=1e-4)
@@ -155,7 +162,7 @@ def test_cutie_aspp_forward_backward_parity(oracle_run, dtype):
         move = eng.params[k].double().cpu() - r["params"][k]
         big = o["grads"][k].abs() > 0.02 * o["grads"][k].abs().max()     # away from g ~ 0, where sign(g) is noise
         frac_same_sign = float((torch.sign(move) == torch.sign(move_ref))[big].double().mean())
-        assert frac_same_sign > (0.9999 if dtype == "f32" else 0.95), (k, frac_same_sign)
+        assert frac_same_sign > {"f32": 0.9999, "bf16": 0.95, "f16": 0.99}[dtype], (k, frac_same_sign)
         assert float(move[big].abs().max()) < 1.01e-4      # |first Adam step| <= lr
 
 
@@ -190,7 +197,7 @@ def test_shapes_other_than_64(oracle_run):
 
 # ------------------------------------------------------------------------------ CUTIE2 (configs 4 / 5): forward
 @pytest.mark.parametrize("variant,B,H,W,Hi", [("aspp", 2, 32, 48, 40), ("dilate", 1, 48, 32, 56)])
-@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("dtype", ["f32", "bf16", "f16"])
 def test_cutie2_forward_parity(variant, B, H, W, Hi, dtype):
     """CUTIE2-ASPP / CUTIE2-dilate inference: image branch (3x3 convs, its own ASPP), positional
     sampling of the image feature map at the token pixels, 1x1 fuser, the CUTIE-ASPP trunk.
@@ -225,9 +232,12 @@ def test_cutie2_forward_parity(variant, B, H, W, Hi, dtype):
     print(variant, dtype, "rel-L2 per layer", {k: "%.1e" % v for k, v in report.items()})
     # bf16: the same ~5e-3 per layer as CUTIE-ASPP, compounded over 21 / 26 layers (see the module
     # docstring); the bound is the measured level with margin, not the 2e-2 target
-    tol = 1e-4 if dtype == "f32" else 1.5e-1
+    tol = {"f32": 1e-4, "bf16": 1.5e-1, "f16": 2e-2}[dtype]
     for name, e in report.items():
         assert e < tol, (name, e)
+    if dtype in ("f32", "f16"):
+        agree = float((eng.get(P, "softmax").cpu().argmax(-1) == ref["softmax"].argmax(-1)).float().mean())
+        print(variant, dtype, "argmax agreement over all cells %.5f" % agree)
     if dtype == "f32":
         assert rel(eng.get(P, "cls_logits")[..., :9], ref["cls_logits"]) < 1e-4
         agree = float((eng.get(P, "softmax").cpu().argmax(-1) == ref["softmax"].argmax(-1)).float().mean())
