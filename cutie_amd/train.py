@@ -10,6 +10,7 @@ New: data parallelism (cutie_amd.parallel) - each rank runs the step on its shar
 hard negative mining is per replica (SURVEY.md 8e caveat).
 """
 import math
+import os
 
 import torch
 
@@ -32,7 +33,11 @@ class Trainer(object):
         self.m = torch.zeros_like(engine.params_flat)
         self.v = torch.zeros_like(engine.params_flat)
         self.rank, self.world = dist_info()
-        self.buckets = GradBuckets(engine.grads_flat, engine.n_conv_w, n_buckets) if self.world > 1 else None
+        # CUTIE_DP_FORCE_BUCKETS=1: take the bucketed all-reduce path in a one-rank group too (rehearsal
+        # of the multi-GPU step on a single GPU; a one-rank all-reduce leaves the gradients as they are)
+        import torch.distributed as dist
+        forced = os.environ.get("CUTIE_DP_FORCE_BUCKETS") == "1" and dist.is_available() and dist.is_initialized()
+        self.buckets = GradBuckets(engine.grads_flat, engine.n_conv_w, n_buckets) if (self.world > 1 or forced) else None
 
     def step(self, batch, fetch=True):
         """batch: {'grid_table', 'gt_classes'[, 'data_image', 'ps_1d_indices']} as next_batch() returns
