@@ -94,6 +94,49 @@ __global__ __launch_bounds__(256) void batch_gather_kernel(const typename elem<D
     }
 }
 
+// backward of batch_gather: dfeat[b, idx[b,cell], :] += dout[b, cell, :] (f32 accumulate).  Grid cells
+// without a token all point at pixel 0 (data_loader_json.py:554-555 leaves ps_x = ps_y = 0), so
+// that row is summed in registers, then LDS, then one atomic per workgroup and channel.
+template <int DT>
+__global__ __launch_bounds__(256) void batch_scatter_add_kernel(const typename elem<DT>::type* __restrict__ dout,
+                                                                int ld_dout, const int32_t* __restrict__ idx,
+                                                                int n_cells, int n_src, int C4,
+                                                                float* __restrict__ dfeat, int cells_per_wg) {
+    __shared__ float4 red[256];
+    const int b = blockIdx.y;
+    const int rows_par = 256 / C4;
+    const int q = threadIdx.x % C4;
+    const int sub = threadIdx.x / C4;
+    float4 acc0 = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int c0 = blockIdx.x * cells_per_wg;
+    const int c1 = min(n_cells, c0 + cells_per_wg);
+    if (sub < rows_par) {
+        for (int cell = c0 + sub; cell < c1; cell += rows_par) {
+            int s = idx[(int64_t)b * n_cells + cell];
+            s = s < 0 ? 0 : (s >= n_src ? n_src - 1 : s);
+            const float4 g = load4(dout + ((int64_t)b * n_cells + cell) * ld_dout + q * 4);
+            if (s == 0) {
+                acc0.x += g.x; acc0.y += g.y; acc0.z += g.z; acc0.w += g.w;
+            } else {
+                float* dst = dfeat + (((int64_t)b * n_src + s) * C4 + q) * 4;
+                atomicAdd(dst + 0, g.x); atomicAdd(dst + 1, g.y);
+                atomicAdd(dst + 2, g.z); atomicAdd(dst + 3, g.w);
+            }
+        }
+    }
+    red[threadIdx.x] = acc0;
+    __syncthreads();
+    if (threadIdx.x < C4) {
+        float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int s = 0; s < rows_par; ++s) {
+            const float4 a = red[s * C4 + q];
+            s0.x += a.x; s0.y += a.y; s0.z += a.z; s0.w += a.w;
+        }
+        float* d0 = dfeat + ((int64_t)b * n_src * C4 + q) * 4;
+        atomicAdd(d0 + 0, s0.x); atomicAdd(d0 + 1, s0.y); atomicAdd(d0 + 2, s0.z); atomicAdd(d0 + 3, s0.w);
+    }
+}
+
 template <int SDT, int DDT>
 __global__ __launch_bounds__(256) void convert_kernel(const typename elem<SDT>::type* __restrict__ src, int ld_src,
                                                       typename elem<DDT>::type* __restrict__ dst, int ld_dst,
@@ -163,6 +206,24 @@ extern "C" int cutie_batch_gather(const void* feat, int ld_feat, int n_src, cons
         hipLaunchKernelGGL(batch_gather_kernel<DT>, dim3(g), dim3(256), 0, stream,
                            (const typename elem<DT>::type*)feat, ld_feat, n_src, idx, n_cells, B, C / 4,
                            (typename elem<DT>::type*)out, ld_out));
+    CUTIE_CHECK_LAUNCH();
+    return CUTIE_OK;
+}
+
+extern "C" int cutie_batch_scatter_add(const void* dout, int ld_dout, int dtype, const int32_t* idx, int n_cells,
+                                       int n_src, int B, int C, float* dfeat, cutie_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    CUTIE_CHECK_ARG(B >= 0 && n_cells >= 0 && n_src >= 1 && C >= 4 && (C % 4) == 0 && C <= 1024, "batch_scatter_add: bad sizes");
+    CUTIE_CHECK_ARG((ld_dout % 4) == 0 && ld_dout >= C, "batch_scatter_add: ld_dout=%d", ld_dout);
+    if (B == 0 || n_cells == 0) return CUTIE_OK;
+    CUTIE_CHECK_ARG(dout && idx && dfeat && cutie::aligned16(dfeat), "batch_scatter_add: null or misaligned pointer");
+    CUTIE_CHECK_ARG(B <= 65535, "batch_scatter_add: B=%d", B);
+    const int cells_per_wg = 512;
+    const dim3 grid((unsigned)cutie::cdiv(n_cells, cells_per_wg), (unsigned)B);
+    CUTIE_DISPATCH_DTYPE(dtype, DT,
+        hipLaunchKernelGGL(batch_scatter_add_kernel<DT>, grid, dim3(256), 0, stream,
+                           (const typename elem<DT>::type*)dout, ld_dout, idx, n_cells, n_src, C / 4, dfeat,
+                           cells_per_wg));
     CUTIE_CHECK_LAUNCH();
     return CUTIE_OK;
 }

@@ -265,6 +265,16 @@ def adam_step(p, g, m, v, lr_t, beta1, beta2, eps, gnorm_sq, clip, grad_scale=1.
          float(eps), ptr(gnorm_sq), float(clip), float(grad_scale), stream())
 
 
+def batch_scatter_add(dout, idx, dfeat):
+    """dout [B, n_cells, >=C] view; idx int32 [B, n_cells]; dfeat f32 [B, n_src, C] contiguous, caller-zeroed."""
+    B, n_src, C = dfeat.shape
+    if dfeat.dtype != torch.float32 or not dfeat.is_contiguous():
+        raise capi.CutieError("batch_scatter_add: dfeat must be contiguous f32")
+    call("cutie_batch_scatter_add", ptr(dout), ld_of(dout), dt_of(dout), ptr(idx), idx.shape[1], n_src, B, C,
+         ptr(dfeat), stream())
+    return dfeat
+
+
 def batch_gather(feat, idx, out):
     """feat [B, n_src, C]; idx int32 [B, n_cells]; out [B, n_cells, >=C] view."""
     B, n_src, C = feat.shape

@@ -136,6 +136,7 @@ class Engine(object):
         P.key, P.B, P.H, P.W, P.Hi = key, B, H, W, Hi
         nodes = net.nodes
         spatial = lambda n: (H, W) if n.domain == "grid" else (Hi, W)
+        P.spatial = spatial
         consumers = {}
         for n in nodes:
             for i in n.inputs:
@@ -213,22 +214,26 @@ class Engine(object):
             return
         net, dev, tdt, B = self.net, self.dev, self.tdt, P.B
         for n in P.convs:
-            if n.domain != "grid":
-                raise NotImplementedError("backward through the CUTIE2 image branch (%s) is not built yet" % n.name)
-        for n in P.convs:
-            P.dz[n.name] = torch.zeros((B, P.H, P.W, _pad(n.channels)), dtype=tdt, device=dev)
-        # gradient buffers for every tensor that a conv or the embedding produces
+            hs, ws = P.spatial(n)
+            P.dz[n.name] = torch.zeros((B, hs, ws, _pad(n.channels)), dtype=tdt, device=dev)
+        # gradient buffers for every tensor that a conv, the embedding or the sampler produces
+        P.ps_acc = {}
         for n in net.nodes:
             if n.op == "conv":
+                hs, ws = P.spatial(n)
                 logits = n.name == net.loss_logits_name
                 ch = _pad(n.channels, 4) if logits else _pad(n.channels)
-                P.dy[n.name] = torch.zeros((B, P.H, P.W, ch), dtype=torch.float32 if logits else tdt, device=dev)
-            elif n.op == "embed":
+                P.dy[n.name] = torch.zeros((B, hs, ws, ch), dtype=torch.float32 if logits else tdt, device=dev)
+            elif n.op in ("embed", "positional_sampling"):
                 P.dy[n.name] = torch.zeros((B, P.H, P.W, _pad(n.channels)), dtype=tdt, device=dev)
+            if n.op == "positional_sampling":
+                # f32 accumulator of the scatter-add into the sampled feature map (image domain)
+                P.ps_acc[n.name] = torch.zeros((B, P.Hi * P.W, n.channels), dtype=torch.float32, device=dev)
         ws_bytes = 0
         for n in P.convs:
             a = n.attrs
-            ws_bytes = max(ws_bytes, ops.conv_wgrad_workspace_bytes(B, P.H, P.W, a["cin"], n.channels, a["kh"], a["kw"]))
+            hs, ws = P.spatial(n)
+            ws_bytes = max(ws_bytes, ops.conv_wgrad_workspace_bytes(B, hs, ws, a["cin"], n.channels, a["kh"], a["kw"]))
         P.wgrad_ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
         P.scratch = torch.zeros(capi.REDUCE_SCRATCH, dtype=torch.float32, device=dev)
         P.hnm_ws = torch.empty(ops.hnm_workspace_bytes(B * P.H * P.W), dtype=torch.uint8, device=dev)
@@ -256,12 +261,34 @@ class Engine(object):
                             break
                         o += i.channels
                     walk(c.name, off + o)
-                elif c.op in ("global_pool", "softmax"):
-                    pass
+                elif c.op in ("global_pool", "softmax", "positional_sampling"):
+                    pass        # sampler: its scatter-add is added by loss_backward (_sampler_consumers)
                 else:
                     raise NotImplementedError("gradient through %s (%s)" % (c.name, c.op))
         walk(name, 0)
         return segs
+
+    def _sampler_consumers(self, P, name):
+        """positional_sampling nodes that gather from tensor `name` (their input 0)"""
+        return [c for c in P.consumers.get(name, []) if c.op == "positional_sampling" and c.inputs[0].name == name]
+
+    def _backprop_into(self, P, n):
+        """dy of node n's output from everything that consumes it."""
+        segs = self._grad_segments(P, n.name)
+        samplers = self._sampler_consumers(P, n.name)
+        if samplers:
+            # tf.batch_gather's gradient: scatter-add of the sampler's output gradient (model_framework.py:73-86)
+            if segs or len(samplers) > 1:
+                raise NotImplementedError("%s feeds a sampler and other layers: mixed gradient not built" % n.name)
+            ps = samplers[0]
+            acc = P.ps_acc[ps.name]
+            acc.zero_()
+            C = ps.channels
+            dps = P.dy[ps.name]
+            ops.batch_scatter_add(dps.as_strided((P.B, P.H * P.W, C), (dps.stride(0), dps.stride(2), 1)), P.ps, acc)
+            ops.convert(acc.view(P.B, P.Hi, P.W, C), P.dy[n.name][..., :C])
+        elif segs:
+            ops.conv_fwd(segs, P.dy[n.name], n.channels)
 
     # ------------------------------------------------------------------ execution
     def forward(self, grid, image=None, ps_1d_indices=None, labels=None):
@@ -365,7 +392,7 @@ class Engine(object):
             if n.op == "conv":
                 a = n.attrs
                 if n.name != lname:
-                    ops.conv_fwd(self._grad_segments(P, n.name), P.dy[n.name], n.channels)
+                    self._backprop_into(P, n)
                 dy = P.dy[n.name][..., :n.channels]
                 av = P.a[n.name][..., :n.channels]
                 ops.in_bwd_stats(dy, av, P.stats[n.name], P.red[n.name])
@@ -378,8 +405,10 @@ class Engine(object):
                     off, cnt, _ = self.offsets[n.name + "/weights"]
                     ops.l2_add(self.params_flat[off:off + cnt], self.grads_flat[off:off + cnt], wd, P.reg, P.scratch, ls)
                     on_ready(_pad(off + cnt, 64))
+            elif n.op == "positional_sampling":
+                self._backprop_into(P, n)
             elif n.op == "embed":
-                ops.conv_fwd(self._grad_segments(P, n.name), P.dy[n.name], n.channels)
+                self._backprop_into(P, n)
                 ops.embed_bwd(P.grid, P.dy[n.name][..., :n.channels], self.grads[n.name + "/weights"])
                 P.d_embed = P.dy[n.name]
         # bias gradients: fold the per-sample partials of every layer in one launch

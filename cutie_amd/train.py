@@ -45,7 +45,8 @@ class Trainer(object):
         eng = self.eng
         if self.iter != 0 and self.lr_decay_step and self.iter % self.lr_decay_step == 0:
             self.lr *= self.lr_decay_factor
-        P = eng.forward(batch["grid_table"], labels=batch["gt_classes"])
+        P = eng.forward(batch["grid_table"], image=batch.get("data_image"), ps_1d_indices=batch.get("ps_1d_indices"),
+                        labels=batch["gt_classes"])
         if self.check_inputs:
             eng.check_inputs(P)
         if self.buckets is not None:

@@ -249,6 +249,13 @@ int cutie_adam_step(float* p, const float* g, float* m, float* v, int64_t n, flo
 int cutie_batch_gather(const void* feat, int ld_feat, int n_src, const int32_t* idx, int n_cells,
                        int B, int C, void* out, int ld_out, int dtype, cutie_stream_t stream);
 
+/* backward of K13 (the gradient tf.gradients derives for tf.batch_gather):
+ * dfeat[b, idx[b, cell], :] += dout[b, cell, :], idx clamped as in the forward; dfeat is a dense
+ * f32 [B, n_src, C] accumulator that the caller zeroes (float atomics; the row of index 0, where
+ * every token-less grid cell points, is pre-reduced per workgroup). */
+int cutie_batch_scatter_add(const void* dout, int ld_dout, int dtype, const int32_t* idx, int n_cells,
+                            int n_src, int B, int C, float* dfeat, cutie_stream_t stream);
+
 /* dtype conversion of a [n_rows, C] view (used for the image input and f32 <-> bf16 / f16 views) */
 int cutie_convert(const void* src, int ld_src, int src_dtype, void* dst, int ld_dst,
                   int dst_dtype, int64_t n_rows, int C, cutie_stream_t stream);

@@ -1,4 +1,5 @@
-"""ORACLE (test infrastructure, not product code): CPU restatement of the CUTIE2 forward graphs.
+"""ORACLE (test infrastructure, not product code): CPU restatement of the CUTIE2 graphs (forward, and
+loss + gradients through autograd).
 
 Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
 PARITY UNPINNED against TensorFlow, for the reasons given in oracle/cutie_oracle.py; the ops are
@@ -18,7 +19,7 @@ from collections import OrderedDict
 
 import torch
 
-from .cutie_oracle import cbrn, global_pool
+from .cutie_oracle import build_loss, cbrn, global_pool
 
 # (op, name, inputs, args);  conv args = (kh, kw, cout, rate)
 TRUNK = [
@@ -130,8 +131,9 @@ def init_params(graph, num_vocabs, embedding_size, num_classes, seed=0, dtype=to
     return params
 
 
-def forward(graph, params, grid, image, ps_1d_indices, activation="relu"):
-    """grid int [B,H,W]; image [B,Hi,W,3]; ps_1d_indices int [B,H*W] -> dict of every named layer."""
+def forward(graph, params, grid, image, ps_1d_indices, activation="relu", masks=None):
+    """grid int [B,H,W]; image [B,Hi,W,3]; ps_1d_indices int [B,H*W] -> dict of every named layer.
+    masks: optional layer name -> 0/1 ReLU pattern (see cutie_oracle.cbrn)."""
     if grid.dim() == 4:
         grid = grid[..., 0]
     L = OrderedDict(data_grid=grid, data_image=image, ps_1d_indices=ps_1d_indices)
@@ -140,7 +142,8 @@ def forward(graph, params, grid, image, ps_1d_indices, activation="relu"):
             L[name] = params[name + "/weights"][grid.long()]
         elif op == "conv":
             act = activation if name == "cls_logits" else "relu"
-            L[name] = cbrn(L[inputs[0]], params[name + "/weights"], params[name + "/biases"], args[3], activation=act)
+            L[name] = cbrn(L[inputs[0]], params[name + "/weights"], params[name + "/biases"], args[3], activation=act,
+                           mask=masks.get(name) if masks else None)
         elif op == "concat":
             L[name] = torch.cat([L[i] for i in inputs], dim=3)
         elif op == "global_pool":
@@ -150,3 +153,19 @@ def forward(graph, params, grid, image, ps_1d_indices, activation="relu"):
         elif op == "softmax":
             L[name] = torch.softmax(L[inputs[0]], dim=-1)
     return L
+
+
+def loss_and_grads(graph, params, grid, image, ps_1d_indices, labels, hard_negative_ratio=3, weight_decay=5e-4,
+                   masks=None, cell_weights=None):
+    """model_cutie2.py:114-147 (the same loss as model_cutie.py:107-140) + tf.gradients of total_loss
+    w.r.t. every variable, by autograd over the restated graph."""
+    ps = OrderedDict((k, v.detach().clone().requires_grad_(True)) for k, v in params.items())
+    layers = forward(graph, ps, grid, image, ps_1d_indices, masks=masks)
+    for t in layers.values():
+        if torch.is_tensor(t) and t.requires_grad:
+            t.retain_grad()
+    model_loss, reg, total, _logits, _sm = build_loss(ps, layers, labels, hard_negative_ratio, weight_decay, cell_weights)
+    total.backward()
+    return {"model_loss": model_loss.detach(), "reg_loss": reg.detach(), "total_loss": total.detach(), "layers": layers,
+            "grads": OrderedDict((k, v.grad) for k, v in ps.items()),
+            "dlayers": OrderedDict((k, t.grad) for k, t in layers.items() if torch.is_tensor(t) and t.grad is not None)}

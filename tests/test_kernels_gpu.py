@@ -641,3 +641,23 @@ def test_f16_training_recovers_from_overflow():
     assert 1 < skipped < 40 and np.isfinite(out["global_norm"])
     assert not torch.equal(eng.params_flat, before)
     assert np.isfinite(losses[-1]) and losses[-1] < losses[0]
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16", "f16"])
+def test_batch_scatter_add(ops, dt):
+    """backward of batch_gather: most cells point at row 0 (token-less cells), some collide elsewhere,
+    out-of-range indices clamp exactly as the forward does."""
+    g = torch.Generator().manual_seed(14)
+    B, n_cells, n_src, C = 3, 1500, 700, 32
+    idx = torch.randint(0, n_src, (B, n_cells), generator=g, dtype=torch.int32)
+    idx[torch.rand((B, n_cells), generator=g) < 0.7] = 0
+    idx[0, 3], idx[0, 4], idx[1, 7] = -5, n_src + 9, idx[1, 8]
+    dout = torch.randn((B, n_cells, C), generator=g).to(TDT[dt])
+    wide = torch.zeros((B, n_cells, C + 32), dtype=TDT[dt], device=DEV)
+    wide[..., :C] = dout.to(DEV)
+    acc = torch.zeros((B, n_src, C), dtype=torch.float32, device=DEV)
+    ops.batch_scatter_add(wide[..., :C], idx.to(DEV), acc)
+    ref = torch.zeros((B, n_src, C), dtype=torch.float64)
+    for b in range(B):
+        ref[b].index_add_(0, idx[b].clamp(0, n_src - 1).long(), dout[b].double())
+    assert relerr(acc, ref) < 1e-5

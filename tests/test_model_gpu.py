@@ -254,3 +254,60 @@ def test_cutie2_needs_its_image_inputs():
     grid, _ = make_inputs(1, 16, 16, 1)
     with pytest.raises((CutieError, KeyError, TypeError, ValueError)):
         eng.forward(grid)
+
+
+# ------------------------------------------------------------------------------ CUTIE2: loss + backward
+@pytest.mark.parametrize("variant,B,H,W,Hi", [("aspp", 2, 32, 48, 40), ("dilate", 1, 48, 32, 56)])
+@pytest.mark.parametrize("dtype", ["f32", "f16"])
+def test_cutie2_backward_parity(variant, B, H, W, Hi, dtype):
+    """tf.gradients of CUTIE2's total loss (model_cutie2.py:114-147, main_train_json.py:152) through the
+    fuser, the sampler (scatter-add into the image feature map, with most cells pointing at pixel 0
+    as token-less cells do) and the 3x3 image branch.  Oracle: autograd over oracle/cutie2_oracle.py on
+    the device's ReLU pattern and hard-negative selection (PARITY UNPINNED against TensorFlow)."""
+    from oracle import cutie2_oracle as c2
+    from cutie_amd.runtime import Engine
+    from cutie_amd.train import Trainer
+    if variant == "aspp":
+        from cutie_amd.model_cutie2_aspp import CUTIE2
+    else:
+        from cutie_amd.model_cutie2_dilate import CUTIE2
+    graph = c2.GRAPHS[variant]
+    g = torch.Generator().manual_seed(12)
+    grid, _ = make_inputs(B, H, W, 6)
+    labels = torch.zeros((B, H, W), dtype=torch.int64)
+    fg = (grid > 0) & (torch.rand((B, H, W), generator=g) < 0.3)
+    labels[fg] = torch.randint(1, 9, (int(fg.sum()),), generator=g)
+    image = torch.rand((B, Hi, W, 3), generator=g) - 0.5
+    ps = torch.randint(1, Hi * W - 1, (B, H * W), generator=g)
+    ps[(grid == 0).reshape(B, -1)] = 0                       # data_loader_json.py:554-555: no token -> pixel 0
+    ps[:, 5] = ps[:, 6]                                      # two cells sampling one pixel
+    params = c2.init_params(graph, V, E, 9, seed=2)
+
+    net = CUTIE2(V, 9, params_ns())
+    net.build_loss()
+    eng = Engine(net, DEV, dtype=dtype)
+    eng.load_params(params)
+    P = eng.forward(grid.unsqueeze(-1), image=image, ps_1d_indices=ps, labels=labels)
+    eng.loss_backward(P)
+    torch.cuda.synchronize()
+    S = eng.loss_scale_value()[0]
+    conv_names = [n.name for n in net.nodes if n.op == "conv"]
+    masks = {k: (P.a[k][..., :net.layers[k].channels] > 0).double().cpu() for k in conv_names}
+    o = c2.loss_and_grads(graph, params, grid, image.double(), ps, labels, masks=masks,
+                          cell_weights=P.weight.double().cpu())
+    ml, rg, tl = eng.losses(P)
+    tol = {"f32": 1e-3, "f16": 3e-2}[dtype]
+    assert abs(ml - float(o["model_loss"])) < tol * abs(float(o["model_loss"]))
+    assert abs(rg - float(o["reg_loss"])) < 1e-4 * abs(float(o["reg_loss"]))
+    sampled = "image_featuremap" if variant == "aspp" else "image_encoder1_8"
+    dl = {k: rel2(P.dy[k][..., :o["dlayers"][k].shape[-1]].double() / S, o["dlayers"][k])[0]
+          for k in ("positional_sampling", sampled, "image_encoder1_1", "feature_fuser", "embedding")}
+    print(variant, dtype, "d(layer) rel-L2", {k: "%.1e" % v for k, v in dl.items()})
+    gerr = {k: rel2(eng.grads[k], gr)[0] for k, gr in o["grads"].items()}
+    print(variant, dtype, "grad rel-L2", {k: "%.1e" % v for k, v in gerr.items()})
+    for k, e in list(dl.items()) + list(gerr.items()):
+        assert e < tol, (k, e)
+    # and one optimiser step runs end to end on the CUTIE2 batch dict
+    tr = Trainer(eng, learning_rate=1e-4)
+    out = tr.step({"grid_table": grid.unsqueeze(-1), "gt_classes": labels, "data_image": image, "ps_1d_indices": ps})
+    assert np.isfinite(out["total_loss"]) and np.isfinite(out["global_norm"]) and out["global_norm"] > 0
