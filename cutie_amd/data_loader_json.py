@@ -57,6 +57,52 @@ def _opt(params, name, default):
     return getattr(params, name) if hasattr(params, name) else default
 
 
+class _Prefetcher(object):
+    def __init__(self, fn, depth):
+        import queue
+        import threading
+        self._q = queue.Queue(maxsize=max(1, int(depth)))
+        self._stop = threading.Event()
+        self._fn = fn
+        self._t = threading.Thread(target=self._run, name='cutie-prefetch', daemon=True)
+        self._t.start()
+
+    def _run(self):
+        import queue
+        while not self._stop.is_set():
+            try:
+                item = ('ok', self._fn())
+            except BaseException as e:          # hand the error to the consumer, then stop
+                item = ('err', e)
+            while not self._stop.is_set():
+                try:
+                    self._q.put(item, timeout=0.1)
+                    break
+                except queue.Full:
+                    continue
+            if item[0] == 'err' or item[1] is None:     # fetch_test_data ends a pass with None
+                return
+
+    def __iter__(self):
+        return self
+
+    def __next__(self):
+        if self._stop.is_set():
+            raise StopIteration
+        kind, val = self._q.get()
+        if kind == 'err':
+            self.close()
+            raise val
+        if val is None:
+            self.close()
+            raise StopIteration
+        return val
+
+    def close(self):
+        self._stop.set()
+        self._t.join(timeout=5.0)
+
+
 class DataLoader(object):
     """grid tables producer (reference: data_loader_json.py:34)"""
 
@@ -224,6 +270,13 @@ class DataLoader(object):
                 break
         return self._batch(mapped, images, ps_1d_indices, rows, cols)
 
+    def prefetch(self, depth=2, fetch='next_batch'):
+        """Iterator over `fetch()` results produced `depth` batches ahead on a background thread, so
+        that the host half of a batch (shape choice, packing, the read-back the evaluation dicts need)
+        overlaps the device step instead of serialising with it as main_train_json.py:228 does.
+        Batches come out in the order the thread drew them; call .close() (or exhaust it) to stop."""
+        return _Prefetcher(getattr(self, fetch), depth)
+
     def fetch_validation_data(self):
         """:210-272 (one document; the reference takes max(rows_target, .) for both axes, :223-224)"""
         while True:
@@ -310,26 +363,40 @@ class DataLoader(object):
 
         Per token (data_loader_json.py:462-470,:510): box, dict id = word_to_index[text],
         entity_id*num_classes + class_id; per document its extent (left, top, right, bottom)."""
-        n_tok = sum(len(d) for d in docs)
-        tok_box = np.zeros((n_tok, 4), dtype=np.int32)
-        tok_id = np.zeros((n_tok,), dtype=np.int32)
-        tok_ecid = np.zeros((n_tok,), dtype=np.int32)
-        tok_cls = np.zeros((n_tok,), dtype=np.int32)
-        extent = np.zeros((len(docs), 4), dtype=np.int32)
+        packed = [self._packed_doc(doc, labels) for doc in docs]
         doc_off = np.zeros((len(docs) + 1,), dtype=np.int32)
-        t = 0
-        for b, doc in enumerate(docs):
-            for item in doc:
-                file_name, text, word_id, box, ext = item[0], item[1], item[2], item[3], item[4]
-                tok_box[t] = box
-                tok_id[t] = self.word_to_index[text]
-                entity_id, class_id = self._dress_class(file_name, word_id, labels)
-                tok_ecid[t] = entity_id * self.num_classes + class_id
-                tok_cls[t] = class_id
-                extent[b] = ext          # the reference uses each item's own copy; they are equal
-                t += 1
-            doc_off[b + 1] = t
+        doc_off[1:] = np.cumsum([len(p[1]) for p in packed])
+        cat = lambda k, shape, : (np.concatenate([p[k] for p in packed]) if packed else np.zeros(shape, dtype=np.int32))
+        tok_box, tok_id, tok_ecid, tok_cls = cat(0, (0, 4)), cat(1, (0,)), cat(2, (0,)), cat(3, (0,))
+        extent = np.stack([p[4] for p in packed]) if packed else np.zeros((0, 4), dtype=np.int32)
         return tok_box, tok_id, tok_ecid, tok_cls, extent, doc_off
+
+    def _packed_doc(self, doc, labels):
+        """int32 arrays of one document, built once: a document is mapped again every time it is
+        drawn (and at every augmented shape), its tokens, dictionary ids and classes do not change
+        after load time (the per-token Python loop was the host cost of a batch)."""
+        cache = self.__dict__.setdefault('_pack_cache', {})
+        key = (id(doc), id(labels))
+        hit = cache.get(key)
+        if hit is not None and hit[0] is doc and hit[1] is labels:
+            return hit[2]
+        n = len(doc)
+        box = np.zeros((n, 4), dtype=np.int32)
+        tid = np.zeros((n,), dtype=np.int32)
+        ecid = np.zeros((n,), dtype=np.int32)
+        cls = np.zeros((n,), dtype=np.int32)
+        ext = np.zeros((4,), dtype=np.int32)
+        for t, item in enumerate(doc):
+            file_name, text, word_id = item[0], item[1], item[2]
+            box[t] = item[3]
+            tid[t] = self.word_to_index[text]
+            entity_id, class_id = self._dress_class(file_name, word_id, labels)
+            ecid[t] = entity_id * self.num_classes + class_id
+            cls[t] = class_id
+            ext[:] = item[4]             # the reference uses each item's own copy; they are equal
+        packed = (box, tid, ecid, cls, ext)
+        cache[key] = (doc, labels, packed)
+        return packed
 
     def _positional_mapping(self, docs, labels, rows, cols):
         """:437-577 on the GPU.  Returns the reference's 9-tuple

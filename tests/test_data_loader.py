@@ -204,6 +204,49 @@ def test_pack_documents(loader):
     assert tok_cls.tolist() == [g["class_id"] for g in gold]
 
 
+def test_pack_documents_caches_per_document_and_concatenates(loader):
+    doc = loader.training_docs[0]
+    first = loader.pack_documents([doc, doc[:40], []], loader.training_labels)
+    again = loader.pack_documents([doc, doc[:40], []], loader.training_labels)
+    for a, b in zip(first, again):
+        assert np.array_equal(a, b) and a.dtype == np.int32
+    tok_box, tok_id, tok_ecid, tok_cls, extent, doc_off = first
+    assert doc_off.tolist() == [0, 366, 366 + 40, 366 + 40] and tok_box.shape == (406, 4) and extent.shape == (3, 4)
+    assert np.array_equal(tok_id[366:], tok_id[:40]) and extent[2].tolist() == [0, 0, 0, 0]
+    assert loader._packed_doc(doc, loader.training_labels) is loader._packed_doc(doc, loader.training_labels)
+    empty = loader.pack_documents([], loader.training_labels)
+    assert empty[0].shape == (0, 4) and empty[5].tolist() == [0]
+
+
+def test_prefetch_keeps_order_passes_errors_and_stops():
+    from cutie_amd.data_loader_json import _Prefetcher
+    import threading
+    calls = []
+
+    def fetch():
+        calls.append(threading.current_thread().name)
+        if len(calls) == 4:
+            return None                       # fetch_test_data's end-of-pass marker
+        return len(calls)
+    it = _Prefetcher(fetch, depth=2)
+    assert list(it) == [1, 2, 3] and set(calls) == {"cutie-prefetch"}
+
+    def boom():
+        raise IndexError("token outside the grid")
+    it = _Prefetcher(boom, depth=1)
+    with pytest.raises(IndexError):
+        next(it)
+    n = [0]
+
+    def forever():
+        n[0] += 1
+        return n[0]
+    it = _Prefetcher(forever, depth=2)
+    assert next(it) == 1 and next(it) == 2
+    it.close()
+    assert not it._t.is_alive()
+
+
 def test_strategy2_is_refused(workdir):
     ld = DataLoader(make_params(workdir, positional_mapping_strategy=2), update_dict=False,
                     load_dictionary=True, verbose=False)
@@ -272,3 +315,28 @@ def test_next_batch_and_fetch_on_gpu(workdir):
     npz = np.load(os.path.join(GOLD, "faktura1_grids.npz"))
     assert np.array_equal(v["grid_table"], npz["r64c64s1_grid"].reshape(1, 64, 64, 1))
     assert ld.fetch_test_data() is None
+
+
+@pytest.mark.gpu
+def test_prefetched_batches_feed_the_train_step(workdir):
+    """loader thread ahead of the step: batches built on the background thread are
+    the ones a direct call builds, and the trainer consumes their device tensors"""
+    import types
+    import torch
+    from cutie_amd.model_cutie_aspp import CUTIERes
+    from cutie_amd.runtime import Engine
+    from cutie_amd.train import Trainer
+    ld = DataLoader(make_params(workdir, batch_size=1), update_dict=False, load_dictionary=True, verbose=False)
+    p = types.SimpleNamespace(embedding_size=128, weight_decay=5e-4, hard_negative_ratio=3, batch_size=1)
+    net = CUTIERes(20000, ld.num_classes, p)
+    net.build_loss()
+    tr = Trainer(Engine(net, "cuda:0", dtype="f16", seed=0), learning_rate=1e-3)
+    it = ld.prefetch(depth=2)
+    losses = []
+    for k, b in zip(range(6), it):
+        assert (b["grid_table"] != 0).sum() == 366 and b["device"]["grid_table"].is_cuda
+        assert torch.equal(b["device"]["grid_table"].cpu(), torch.from_numpy(b["grid_table"]))
+        out = tr.step({"grid_table": b["device"]["grid_table"], "gt_classes": b["device"]["gt_classes"]})
+        losses.append(out["total_loss"])
+    it.close()
+    assert len(losses) == 6 and all(np.isfinite(l) for l in losses) and losses[-1] < losses[0]
