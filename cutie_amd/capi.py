@@ -62,7 +62,7 @@ SIGNATURES = {
     "cutie_in_bwd_apply": (_i, [_vp, _i, _i, _vp, _i, _i, _vp, _f, _vp, _i, _vp, _i, _i, _vp, _i, _i, _i, _vp]),
     "cutie_sum_rows": (_i, [_vp, _i, _i, _vp, _i, _vp]),
     "cutie_sum_rows_batched": (_i, [_c.POINTER(SumRowsDesc), _i, _i, _i, _vp]),
-    "cutie_spatial_mean_bcast": (_i, [_vp, _i, _i, _vp, _i, _i, _i, _i, _i, _vp]),
+    "cutie_spatial_mean_bcast": (_i, [_vp, _i, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "cutie_softmax_ce_fwd": (_i, [_vp, _i, _i, _vp, _i64, _i, _vp, _vp, _vp, _vp]),
     "cutie_hnm_workspace_bytes": (_sz, [_i64]),
     "cutie_hnm_weights": (_i, [_vp, _vp, _i64, _i, _vp, _vp, _vp, _sz, _vp]),

@@ -276,6 +276,24 @@ __global__ __launch_bounds__(256) void mean_bcast_kernel(const TX* __restrict__ 
     }
 }
 
+// second half of the wide-grid global pool: out[b, hw, c] = sums[b][c][0] / HW
+template <int VEC, typename TO>
+__global__ __launch_bounds__(256) void bcast_mean_kernel(const float* __restrict__ sums, TO* __restrict__ out, int ld_out,
+                                                         int HW, int C, int rows_per_wg) {
+    const int CV = C / VEC;
+    const int b = blockIdx.y;
+    const int rows_par = 256 / CV;
+    const int cl = threadIdx.x % CV, sub = threadIdx.x / CV;
+    if (sub >= rows_par) return;
+    vecf<VEC> mv;
+    const float inv = 1.f / (float)HW;
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) mv.v[e] = sums[((int64_t)b * C + cl * VEC + e) * 2] * inv;
+    const int r0 = blockIdx.x * rows_per_wg;
+    const int r1 = min(HW, r0 + rows_per_wg);
+    for (int hw = r0 + sub; hw < r1; hw += rows_par) storev<VEC>(out + ((int64_t)b * HW + hw) * ld_out + cl * VEC, mv);
+}
+
 struct Launch { dim3 grid; int vec; };
 inline int pick_vec(int C, std::initializer_list<int> lds, std::initializer_list<const void*> ptrs) {
     if (C % 4) return 1;
@@ -414,13 +432,28 @@ extern "C" int cutie_sum_rows_batched(const cutie_sum_rows_desc* descs, int n, i
 }
 
 extern "C" int cutie_spatial_mean_bcast(const void* x, int ld_x, int x_dtype, void* out, int ld_out, int out_dtype,
-                                        int B, int HW, int C, cutie_stream_t stream_) {
+                                        int B, int HW, int C, float* scratch, cutie_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     const int vec = pick_vec(C, {ld_x, ld_out}, {x, out});
     CUTIE_CHECK_ARG(B >= 0 && HW >= 1 && C >= 1, "spatial_mean_bcast: bad sizes");
     if (B == 0) return CUTIE_OK;
     CUTIE_CHECK_ARG(x && out && ld_x >= C && ld_out >= C, "spatial_mean_bcast: null pointer or ld < C");
     const int CV = C / vec;
+    if (scratch && CV <= 256) {
+        // wide grid: the per-(b, c) sums by the instance-norm statistics pass (thousands of
+        // workgroups, one f32 atomic per workgroup and channel), then a pure store pass
+        CUTIE_CHECK_HIP(hipMemsetAsync(scratch, 0, (size_t)B * C * 2 * sizeof(float), stream));
+        const int rc = cutie_in_stats(x, ld_x, x_dtype, B, HW, C, scratch, stream_);
+        if (rc != CUTIE_OK) return rc;
+        const int rows_par = 256 / CV;
+        int rows_per_wg = rows_par * 8;
+        const dim3 g((HW + rows_per_wg - 1) / rows_per_wg, B);
+        CUTIE_DISPATCH_DTYPE(out_dtype, ODT, NORM_DISPATCH_VEC(vec,
+            hipLaunchKernelGGL((bcast_mean_kernel<VEC, typename elem<ODT>::type>), g, dim3(256), 0, stream,
+                               (const float*)scratch, (typename elem<ODT>::type*)out, ld_out, HW, C, rows_per_wg)));
+        CUTIE_CHECK_LAUNCH();
+        return CUTIE_OK;
+    }
     const int cv_blk = CV < 16 ? CV : 16;
     const dim3 g((CV + cv_blk - 1) / cv_blk, B);
     CUTIE_DISPATCH_DTYPE(x_dtype, XDT, CUTIE_DISPATCH_DTYPE(out_dtype, ODT, NORM_DISPATCH_VEC(vec,

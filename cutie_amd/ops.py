@@ -207,10 +207,13 @@ def sum_rows(part, out, accumulate=False):
     return out
 
 
-def spatial_mean_bcast(x, out):
+def spatial_mean_bcast(x, out, scratch=None):
+    """scratch: optional f32 tensor of >= B*C*2 elements (clobbered) - selects the wide-grid path"""
     B, HW, C = _bhwc(x)
+    if scratch is not None and (scratch.dtype != torch.float32 or scratch.numel() < B * C * 2):
+        raise capi.CutieError("spatial_mean_bcast: scratch needs %d f32 elements" % (B * C * 2))
     call("cutie_spatial_mean_bcast", ptr(x), ld_of(x), dt_of(x), ptr(out), ld_of(out), dt_of(out), B, HW, C,
-         stream())
+         ptr(scratch), stream())
     return out
 
 

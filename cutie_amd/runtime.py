@@ -193,6 +193,8 @@ class Engine(object):
             P.red[n.name] = P.red_all[so:so + cnt].view(B, n.channels, 2)
             P.dbpart[n.name] = P.red_all[n_stats + so // 2:n_stats + (so + cnt) // 2].view(B, n.channels)
             so += cnt
+        pooled = [n.inputs[0].channels for n in nodes if n.op == "global_pool"]
+        P.pool_scratch = torch.zeros(B * max(pooled) * 2, dtype=torch.float32, device=dev) if pooled else None
         P.oob = torch.zeros(1, dtype=torch.int32, device=dev)
         P.bad = torch.zeros(1, dtype=torch.int32, device=dev)
         N = B * H * W
@@ -328,7 +330,7 @@ class Engine(object):
                 ops.in_apply(P.a[n.name][..., :n.channels], P.stats[n.name], P.view(n.name, n.channels))
             elif n.op == "global_pool":
                 src = n.inputs[0]
-                ops.spatial_mean_bcast(P.view(src.name, src.channels), P.view(n.name, n.channels))
+                ops.spatial_mean_bcast(P.view(src.name, src.channels), P.view(n.name, n.channels), P.pool_scratch)
             elif n.op == "concat":
                 for (src, dst_name, dst) in P.copies:
                     if dst_name == n.name:

@@ -181,9 +181,13 @@ typedef struct cutie_sum_rows_desc {
 int cutie_sum_rows_batched(const cutie_sum_rows_desc* descs, int n, int B, int accumulate, cutie_stream_t stream);
 
 /* K8  Model.global_pool, model_framework.py:309-315: spatial mean broadcast back to HxW
- * (reduce_mean + nearest-neighbour resize), written into a channel slice. */
+ * (reduce_mean + nearest-neighbour resize), written into a channel slice.
+ * scratch (nullable): B*C*2 floats, clobbered; with it the sums are taken by the wide-grid
+ * statistics pass (float atomics) and the broadcast is a pure store pass; without it one
+ * workgroup per (sample, 128 channels) does both in a fixed order. */
 int cutie_spatial_mean_bcast(const void* x, int ld_x, int x_dtype, void* out, int ld_out,
-                             int out_dtype, int B, int HW, int C, cutie_stream_t stream);
+                             int out_dtype, int B, int HW, int C, float* scratch,
+                             cutie_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------
  * K9-K11  per-cell softmax cross-entropy with hard negative mining.   Replaces

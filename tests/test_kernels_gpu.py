@@ -381,13 +381,19 @@ def test_instance_norm_fwd_bwd(ops, dt, C):
     assert relerr(db, da_ref.sum(dim=(0, 1, 2))) < tol
 
 
-def test_spatial_mean_bcast(ops):
+@pytest.mark.parametrize("with_scratch", [False, True])
+@pytest.mark.parametrize("dt,C", [("f32", 256), ("bf16", 256), ("f16", 32), ("f32", 20)])
+def test_spatial_mean_bcast(ops, dt, C, with_scratch):
     g = torch.Generator().manual_seed(4)
-    x = torch.randn((3, 10, 12, 256), generator=g)
-    out = torch.zeros((3, 10, 12, 1024), dtype=torch.float32, device=DEV)
-    ops.spatial_mean_bcast(x.to(DEV), out[..., 768:])
-    assert relerr(out[..., 768:], co.global_pool(x.double())) < 1e-5
-    assert float(out[..., :768].abs().max()) == 0.0
+    tdt = TDT[dt]
+    x = (torch.randn((3, 10, 12, C), generator=g) + 0.5).to(tdt)
+    out = torch.zeros((3, 10, 12, 3 * C + C), dtype=tdt, device=DEV)
+    scratch = torch.full((3 * C * 2 + 5,), 9.0, dtype=torch.float32, device=DEV) if with_scratch else None
+    ops.spatial_mean_bcast(x.to(DEV), out[..., 3 * C:], scratch)
+    assert relerr(out[..., 3 * C:], co.global_pool(x.double())) < {"f32": 1e-5, "bf16": 4e-3, "f16": 5e-4}[dt]
+    assert float(out[..., :3 * C].abs().max()) == 0.0
+    if with_scratch:
+        assert torch.all(scratch[-5:] == 9.0)
 
 
 # ------------------------------------------------------------------------------------ K9-K11
