@@ -98,8 +98,9 @@ __device__ __forceinline__ void glds16(u32x4s_t rsrc, unsigned lds_dst, unsigned
 
 }  // namespace convk
 
-// conv_wide.hip: 16-bit in / out of one type, n_out a multiple of 256, every segment cin a multiple of 64
-int launch_conv_wide(const convk::ConvParams& p, int dtype, hipStream_t stream);
-bool conv_wide_supported(const convk::ConvParams& p);
+// conv_wide.hip: 16-bit in / out of one type, n_out a multiple of 64 (channel tile 256 / 128 / 64), every
+// segment cin a multiple of 64
+int launch_conv_wide(const convk::ConvParams& p, int dtype, int bn, hipStream_t stream);
+int conv_wide_tile(const convk::ConvParams& p);
 
 }  // namespace cutie

@@ -746,15 +746,16 @@ extern "C" int cutie_conv_fwd(const cutie_conv_seg* segs, int n_segs, int B, int
     CUTIE_CHECK_ARG((long long)B * p.tiles_h * p.tiles_w * p.n_tiles_n < (1ll << 31), "conv_fwd: grid too large");
     // wide layers: 256-pixel x 256-channel tiles fed by LDS-DMA (conv_wide.hip)
     static const bool wide_on = !(getenv("CUTIE_CONV_WIDE") && atoi(getenv("CUTIE_CONV_WIDE")) == 0);
-    if (wide_on && dtype != CUTIE_F32 && out_dtype == dtype && cutie::conv_wide_supported(p)) {
+    const int bn = (wide_on && dtype != CUTIE_F32 && out_dtype == dtype) ? cutie::conv_wide_tile(p) : 0;
+    if (bn) {
         ConvParams q = p;
         int th = 16, tcb = 1;
         while (th > 1 && th / 2 >= H && tcb * 16 < W) { th /= 2; tcb *= 2; }
         q.TH = th; q.TWB = tcb;
         q.tiles_h = (int)cutie::cdiv(H, th);
         q.tiles_w = (int)cutie::cdiv(W, tcb * 16);
-        q.n_tiles_n = n_out / 256;
-        if ((long long)B * q.tiles_h * q.tiles_w * q.n_tiles_n < (1ll << 31)) return cutie::launch_conv_wide(q, dtype, stream);
+        q.n_tiles_n = n_out / bn;
+        if ((long long)B * q.tiles_h * q.tiles_w * q.n_tiles_n < (1ll << 31)) return cutie::launch_conv_wide(q, dtype, bn, stream);
     }
     if (dtype == CUTIE_BF16) {
         if (out_dtype == CUTIE_BF16) return launch_conv<CUTIE_BF16, CUTIE_BF16>(p, lds, stream);

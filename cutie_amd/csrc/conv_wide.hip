@@ -24,22 +24,31 @@ namespace {
 using namespace cutie::convk;
 
 constexpr int CW_NT = 512;
-constexpr int CW_A0 = 0, CW_B0 = 65536, CW_BUF = 32768;    // LDS map: A0 A1 B0 B1, 32 KB each
-constexpr int CW_LDS = 131072;
+constexpr int CW_A0 = 0, CW_B0 = 65536, CW_ABUF = 32768;    // LDS map: A0 A1 (32 KB each), B0 B1 (BN * 128 B each)
+template <int BN> struct Shape {
+    static constexpr int WN = BN / 64;          // waves across the channel tile (each owns 64 channels)
+    static constexpr int WM = 8 / WN;           // waves across the 256 pixels
+    static constexpr int MB = 16 / WM;          // 16-pixel blocks per wave: 8 / 4 / 2
+    static constexpr int NB = BN / 64;          // 1-KB pieces of the B tile each wave stages per step
+    static constexpr int NP = 4 + NB;           // pieces per wave and step (A: always 4)
+    static constexpr int BBUF = BN * 128;
+    static constexpr int LDS = CW_B0 + 2 * BBUF;
+};
 
-// bias, ReLU, instance-norm moments, LDS-staged coalesced store of a 256-pixel x 256-channel tile
-template <int DT>
-__device__ __forceinline__ void conv_wide_epilogue(const ConvParams& p, float4_t (&acc)[8][4], char* smem, int b, int h0,
-                                                   int w0, int n0) {
+// bias, ReLU, instance-norm moments, LDS-staged coalesced store of a 256-pixel x BN-channel tile
+template <int DT, int BN>
+__device__ __forceinline__ void conv_wide_epilogue(const ConvParams& p, float4_t (&acc)[Shape<BN>::MB][4], char* smem, int b,
+                                                   int h0, int w0, int n0) {
+    typedef Shape<BN> S;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 2, wn = wave & 3;
+    const int wm = wave / S::WN, wn = wave % S::WN;
     const int li = lane & 15, lg = lane >> 4;
     const int H = p.H, W = p.W, TCB = p.TWB, n_out = p.n_out;
     __syncthreads();
     typedef typename elem<DT>::type TO;
-    TO* Cs = reinterpret_cast<TO*>(smem);  // [256 pixels][256 channels]
+    TO* Cs = reinterpret_cast<TO*>(smem);  // [256 pixels][BN channels]
 #pragma unroll
     for (int n = 0; n < 4; ++n) {
         const int cl = wn * 64 + n * 16 + li;
@@ -47,8 +56,8 @@ __device__ __forceinline__ void conv_wide_epilogue(const ConvParams& p, float4_t
         const float bv = (p.bias && col < n_out) ? p.bias[col] : 0.f;
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-        for (int m = 0; m < 8; ++m) {
-            const int mb = wm * 8 + m;
+        for (int m = 0; m < S::MB; ++m) {
+            const int mb = wm * S::MB + m;
             const int h = h0 + mb / TCB;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -58,7 +67,7 @@ __device__ __forceinline__ void conv_wide_epilogue(const ConvParams& p, float4_t
                 if (!(h < H && w < W)) v = 0.f;
                 s1 += v;
                 s2 += v * v;
-                store_from_f32(Cs + (mb * 16 + lg * 4 + r) * 256 + cl, v);
+                store_from_f32(Cs + (mb * 16 + lg * 4 + r) * BN + cl, v);
             }
         }
         if (p.stats) {
@@ -71,25 +80,28 @@ __device__ __forceinline__ void conv_wide_epilogue(const ConvParams& p, float4_t
         }
     }
     __syncthreads();
-    for (int idx = tid; idx < 256 * 32; idx += CW_NT) {      // 16-byte pieces: 32 per pixel row
-        const int ml = idx >> 5, pc = idx & 31;
+    constexpr int PPR = BN / 8;                                   // 16-byte pieces per pixel row
+    for (int idx = tid; idx < 256 * PPR; idx += CW_NT) {
+        const int ml = idx / PPR, pc = idx % PPR;
         const int mb = ml >> 4;
         const int h = h0 + mb / TCB, w = w0 + (mb % TCB) * 16 + (ml & 15);
         const int col = n0 + pc * 8;
         if (h < H && w < W && col < n_out) {
             TO* dst = reinterpret_cast<TO*>(p.out) + ((long long)(b * H + h) * W + w) * p.ld_out + col;
-            *reinterpret_cast<uint4*>(dst) = *reinterpret_cast<const uint4*>(Cs + ml * 256 + pc * 8);
+            *reinterpret_cast<uint4*>(dst) = *reinterpret_cast<const uint4*>(Cs + ml * BN + pc * 8);
         }
     }
 }
 
-template <int DT>
+template <int DT, int BN>
 __global__ __launch_bounds__(CW_NT) void conv_wide_kernel(ConvParams p) {
+    typedef Shape<BN> S;
+    constexpr int MB = S::MB, NB = S::NB, NP = S::NP;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 2, wn = wave & 3;
+    const int wm = wave / S::WN, wn = wave % S::WN;
     const int li = lane & 15, lg = lane >> 4;
     const unsigned lds0 = (unsigned)(uintptr_t)((lds_void_t*)smem);
     const int H = p.H, W = p.W, TCB = p.TWB, n_out = p.n_out;
@@ -104,33 +116,37 @@ __global__ __launch_bounds__(CW_NT) void conv_wide_kernel(ConvParams p) {
     const int tw = bid % p.tiles_w; bid /= p.tiles_w;
     const int th = bid % p.tiles_h;
     const int b = bid / p.tiles_h;
-    const int h0 = th * TR, w0 = tw * TC, n0 = nt * 256;
+    const int h0 = th * TR, w0 = tw * TC, n0 = nt * BN;
 
-    float4_t acc[8][4];
+    float4_t acc[MB][4];
 #pragma unroll
-    for (int m = 0; m < 8; ++m)
+    for (int m = 0; m < MB; ++m)
 #pragma unroll
         for (int n = 0; n < 4; ++n) acc[m][n] = float4_t{0.f, 0.f, 0.f, 0.f};
 
-    // staging plan: wave w moves 1-KB pieces 4w..4w+3 of the A tile and of the B tile; lane l of
-    // a piece is (row = l >> 3, 16-byte slot = l & 7) and fetches chunk slot ^ swz(row)
-    int a_h[4], a_w[4], a_c16[4], b_row[4], b_c16[4];
+    // staging plan: wave w moves 1-KB pieces 4w..4w+3 of the A tile and NB*w.. of the B tile; lane l
+    // of a piece is (row = l >> 3, 16-byte slot = l & 7) and fetches chunk slot ^ swz(row)
+    int a_h[4], a_w[4], a_c16[4], b_row[NB], b_c16[NB];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        const int r = wave * 32 + k * 8 + (lane >> 3);     // tile pixel / weight row 0..255
+        const int r = wave * 32 + k * 8 + (lane >> 3);     // tile pixel 0..255
         const int mb = r >> 4;
         a_h[k] = h0 + mb / TCB;
         a_w[k] = w0 + (mb % TCB) * 16 + (r & 15);
         a_c16[k] = ((lane & 7) ^ swz(r)) * 16;
+    }
+#pragma unroll
+    for (int k = 0; k < NB; ++k) {
+        const int r = wave * (NB * 8) + k * 8 + (lane >> 3);   // weight row 0..BN-1
         b_row[k] = n0 + r;
-        b_c16[k] = a_c16[k];
+        b_c16[k] = ((lane & 7) ^ swz(r)) * 16;
     }
     // fragment read offsets (bytes from the A / B tile base); + m*2048 / n*2048 per 16-row block
     int a_rd[2], b_rd[2];
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
         const int c16 = ((kk * 4 + lg) ^ ((li >> 1) & 7)) * 16;
-        a_rd[kk] = (wm * 128 + li) * 128 + c16;
+        a_rd[kk] = (wm * (MB * 16) + li) * 128 + c16;
         b_rd[kk] = (wn * 64 + li) * 128 + c16;
     }
     int buf = 0;
@@ -157,15 +173,14 @@ __global__ __launch_bounds__(CW_NT) void conv_wide_kernel(ConvParams p) {
         const long long wbytes = ((long long)(g.kh * g.kw - 1) * g.w_tap_stride + (long long)n_out * g.cin) * 2;
         const u32x4s_t rsrc_w = make_rsrc(g.w, (unsigned)wbytes);
         int a_base[4];
-        unsigned b_base[4];
+        unsigned b_base[NB];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            a_base[k] = (a_h[k] * W + a_w[k]) * g.ld_x * 2 + a_c16[k];
-            b_base[k] = b_row[k] < n_out ? (unsigned)(b_row[k] * g.cin * 2 + b_c16[k]) : BUF_OOB;
-        }
+        for (int k = 0; k < 4; ++k) a_base[k] = (a_h[k] * W + a_w[k]) * g.ld_x * 2 + a_c16[k];
+#pragma unroll
+        for (int k = 0; k < NB; ++k) b_base[k] = b_row[k] < n_out ? (unsigned)(b_row[k] * g.cin * 2 + b_c16[k]) : BUF_OOB;
 
-        // one step's loads: 4 A pieces + 4 B pieces per wave.  `piece` 0..7 so that the pipelined
-        // loop can drop one piece between MFMA groups instead of a burst after the barrier.
+        // one step's loads: 4 A pieces + NB B pieces per wave.  `piece` 0..NP-1 so that the pipelined
+        // loop can drop the pieces between MFMA groups instead of a burst after the barrier.
         int da = 0, sy = 0, sx = 0;
         unsigned db = 0;
         auto step_offsets = [&](int tap, int cc) {
@@ -179,34 +194,36 @@ __global__ __launch_bounds__(CW_NT) void conv_wide_kernel(ConvParams p) {
             if (piece < 4) {
                 const int k = piece;
                 const bool ok = (unsigned)(a_h[k] + sy) < (unsigned)H && (unsigned)(a_w[k] + sx) < (unsigned)W;
-                glds16(rsrc_x, lds0 + CW_A0 + bsel * CW_BUF + wave * 4096 + k * 1024,
+                glds16(rsrc_x, lds0 + CW_A0 + bsel * CW_ABUF + wave * 4096 + k * 1024,
                        ok ? (unsigned)(a_base[k] + da) : BUF_OOB);
             } else {
                 const int k = piece - 4;    // an out-of-range weight row stays out of range after + db
-                glds16(rsrc_w, lds0 + CW_B0 + bsel * CW_BUF + wave * 4096 + k * 1024, b_base[k] + db);
+                glds16(rsrc_w, lds0 + CW_B0 + bsel * S::BBUF + wave * (NB * 1024) + k * 1024, b_base[k] + db);
             }
         };
         auto compute = [&](int bsel, auto prefetch) {
-            const char* At = smem + CW_A0 + bsel * CW_BUF;
-            const char* Bt = smem + CW_B0 + bsel * CW_BUF;
-            uint4 bf0[4], af0[8], bf1[4], af1[8];
+            const char* At = smem + CW_A0 + bsel * CW_ABUF;
+            const char* Bt = smem + CW_B0 + bsel * S::BBUF;
+            uint4 bf0[4], af0[MB], bf1[4], af1[MB];
 #pragma unroll
             for (int n = 0; n < 4; ++n) bf0[n] = *reinterpret_cast<const uint4*>(Bt + b_rd[0] + n * 2048);
 #pragma unroll
-            for (int m = 0; m < 8; ++m) af0[m] = *reinterpret_cast<const uint4*>(At + a_rd[0] + m * 2048);
-            // first K half: between the groups of 4 MFMAs, one 1-KB piece of the next step's tiles
-            // is sent on its way and the second half's fragments are fetched; the scheduling
+            for (int m = 0; m < MB; ++m) af0[m] = *reinterpret_cast<const uint4*>(At + a_rd[0] + m * 2048);
+            // first K half: between the groups of 4 MFMAs the pieces of the next step's tiles are
+            // sent on their way and the second half's fragments are fetched; the scheduling
             // barriers keep hipcc from gathering the loads into one burst
 #pragma unroll
-            for (int m = 0; m < 8; ++m) {
-                prefetch(m);
-                if (m == 3) {
+            for (int m = 0; m < MB; ++m) {
+#pragma unroll
+                for (int q = 0; q < NP; ++q)
+                    if ((q * MB) / NP == m) prefetch(q);
+                if (m == MB / 2 - 1) {
 #pragma unroll
                     for (int n = 0; n < 4; ++n) bf1[n] = *reinterpret_cast<const uint4*>(Bt + b_rd[1] + n * 2048);
                 }
-                if (m >= 4) {
-                    af1[2 * (m - 4)] = *reinterpret_cast<const uint4*>(At + a_rd[1] + (2 * (m - 4)) * 2048);
-                    af1[2 * (m - 4) + 1] = *reinterpret_cast<const uint4*>(At + a_rd[1] + (2 * (m - 4) + 1) * 2048);
+                if (m >= MB / 2) {
+                    af1[2 * (m - MB / 2)] = *reinterpret_cast<const uint4*>(At + a_rd[1] + (2 * (m - MB / 2)) * 2048);
+                    af1[2 * (m - MB / 2) + 1] = *reinterpret_cast<const uint4*>(At + a_rd[1] + (2 * (m - MB / 2) + 1) * 2048);
                 }
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -214,7 +231,7 @@ __global__ __launch_bounds__(CW_NT) void conv_wide_kernel(ConvParams p) {
                 __builtin_amdgcn_sched_barrier(0);
             }
 #pragma unroll
-            for (int m = 0; m < 8; ++m)
+            for (int m = 0; m < MB; ++m)
 #pragma unroll
                 for (int n = 0; n < 4; ++n) mma_frag<DT>(af1[m], bf1[n], acc[m][n]);
         };
@@ -227,7 +244,7 @@ __global__ __launch_bounds__(CW_NT) void conv_wide_kernel(ConvParams p) {
         __builtin_amdgcn_s_barrier();        // the previous segment's last reads of `buf` are done
         step_offsets(tap, cc);
 #pragma unroll
-        for (int q = 0; q < 8; ++q) issue_piece(q, buf);
+        for (int q = 0; q < NP; ++q) issue_piece(q, buf);
         while (true) {
             // taps innermost: consecutive steps read the same 128-byte channel chunk of
             // overlapping pixels, so the A lines are still in L2 (with channels innermost the
@@ -249,7 +266,7 @@ __global__ __launch_bounds__(CW_NT) void conv_wide_kernel(ConvParams p) {
             if (!more) break;
             step_offsets(ntap, nc);
             const int nb = buf ^ 1;
-            compute(buf, [&](int m) { issue_piece(m, nb); });
+            compute(buf, [&](int q) { issue_piece(q, nb); });
             tap = ntap;
             cc = nc;
             buf = nb;
@@ -258,34 +275,47 @@ __global__ __launch_bounds__(CW_NT) void conv_wide_kernel(ConvParams p) {
         buf ^= 1;
     }
 
-    conv_wide_epilogue<DT>(p, acc, smem, b, h0, w0, n0);
+    conv_wide_epilogue<DT, BN>(p, acc, smem, b, h0, w0, n0);
 }
 
 
 }  // namespace
 
-bool conv_wide_supported(const ConvParams& p) {
-    if (p.n_out % 256 != 0 || (p.ld_out * 2) % 16 != 0 || !aligned16(p.out)) return false;
+// channel tile for n_out: 256 where it divides, else 128, else 64; 0 = not a wide-kernel shape
+int conv_wide_tile(const ConvParams& p) {
+    if ((p.ld_out * 2) % 16 != 0 || !aligned16(p.out)) return 0;
     for (int s = 0; s < p.nseg; ++s)
-        if (p.seg[s].cin % 64 != 0 || p.seg[s].kh * p.seg[s].kw > 32) return false;
-    return true;
+        if (p.seg[s].cin % 64 != 0 || p.seg[s].kh * p.seg[s].kw > 32) return 0;
+    if (p.n_out % 256 == 0) return 256;
+    if (p.n_out % 128 == 0) return 128;
+    if (p.n_out % 64 == 0) return 64;
+    return 0;
 }
 
-// p.TH / p.TWB / tiles_* / n_tiles_n must describe 256-pixel x 256-channel tiles
-int launch_conv_wide(const ConvParams& p, int dtype, hipStream_t stream) {
+template <int DT, int BN>
+static int launch_one(const ConvParams& p, hipStream_t stream) {
     const long long grid = (long long)p.B * p.tiles_h * p.tiles_w * p.n_tiles_n;
-    if (dtype == CUTIE_BF16) {
-        CUTIE_CHECK_HIP(hipFuncSetAttribute((const void*)conv_wide_kernel<CUTIE_BF16>, hipFuncAttributeMaxDynamicSharedMemorySize, CW_LDS));
-        hipLaunchKernelGGL(conv_wide_kernel<CUTIE_BF16>, dim3((unsigned)grid), dim3(CW_NT), CW_LDS, stream, p);
-    } else if (dtype == CUTIE_F16) {
-        CUTIE_CHECK_HIP(hipFuncSetAttribute((const void*)conv_wide_kernel<CUTIE_F16>, hipFuncAttributeMaxDynamicSharedMemorySize, CW_LDS));
-        hipLaunchKernelGGL(conv_wide_kernel<CUTIE_F16>, dim3((unsigned)grid), dim3(CW_NT), CW_LDS, stream, p);
-    } else {
+    CUTIE_CHECK_HIP(hipFuncSetAttribute((const void*)conv_wide_kernel<DT, BN>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        Shape<BN>::LDS));
+    hipLaunchKernelGGL((conv_wide_kernel<DT, BN>), dim3((unsigned)grid), dim3(CW_NT), Shape<BN>::LDS, stream, p);
+    CUTIE_CHECK_LAUNCH();
+    return CUTIE_OK;
+}
+
+// p.TH / p.TWB / tiles_* must describe 256-pixel tiles, p.n_tiles_n = n_out / bn
+int launch_conv_wide(const ConvParams& p, int dtype, int bn, hipStream_t stream) {
+    if (dtype != CUTIE_BF16 && dtype != CUTIE_F16) {
         set_error("conv_wide: dtype %d", dtype);
         return CUTIE_E_ARG;
     }
-    CUTIE_CHECK_LAUNCH();
-    return CUTIE_OK;
+    const bool bf = dtype == CUTIE_BF16;
+    switch (bn) {
+        case 256: return bf ? launch_one<CUTIE_BF16, 256>(p, stream) : launch_one<CUTIE_F16, 256>(p, stream);
+        case 128: return bf ? launch_one<CUTIE_BF16, 128>(p, stream) : launch_one<CUTIE_F16, 128>(p, stream);
+        case 64: return bf ? launch_one<CUTIE_BF16, 64>(p, stream) : launch_one<CUTIE_F16, 64>(p, stream);
+    }
+    set_error("conv_wide: channel tile %d", bn);
+    return CUTIE_E_ARG;
 }
 
 }  // namespace cutie

@@ -225,6 +225,12 @@ WIDE_CASES = [
     (1, 7, 80, 192, 512, 3, 5, 2),
     (3, 16, 16, 320, 256, 1, 1, 1),
     (1, 5, 130, 64, 256, 3, 3, 2),
+    # channel tiles 128 and 64 (decoder 512 -> 64, the data gradient into the 128-channel embedding)
+    (2, 64, 64, 256, 128, 3, 5, 1),
+    (1, 64, 64, 512, 64, 3, 5, 1),
+    (1, 33, 50, 64, 384, 3, 5, 4),
+    (2, 20, 64, 128, 192, 1, 1, 1),
+    (1, 40, 64, 64, 64, 3, 5, 16),
 ]
 
 
