@@ -18,8 +18,11 @@ unchanged.  What differs underneath:
     same integer / double arithmetic; it is pinned by tests/golden/faktura1_items.json and
     shapes.json, which the reference's own loader produced.
 
-Not carried over (out of scope): strategy 2 grid expansion
-(raises NotImplementedError), cv2 image loading for CUTIE2 (``_positional_sampling`` takes
+positional_mapping_strategy 2 (the default of the reference's drivers) runs too: its "expansion"
+never triggers - the search for a free slot starts on the cell the strategy-1 shift has just
+freed - so it is strategy 1 (tests/golden/strategy2_cases.json holds the reference's own verdict).
+
+Not carried over (out of scope): cv2 image loading for CUTIE2 (``_positional_sampling`` takes
 already-decoded images through ``image_reader``), the grid visualiser and the unused
 ``_form_label_matrix`` / ``build_gt_pyramid`` stubs.
 """
@@ -232,8 +235,8 @@ class DataLoader(object):
     # ------------------------------------------------------------------ batches (a3)
     def _map_with_expand(self, docs, labels, rows, cols, what):
         out = self._positional_mapping(docs, labels, rows, cols)
-        if out[6] > cols:          # only strategy 2 can grow the grid; not offered here
-            raise NotImplementedError('%s grid expansion (strategy 2) is not built' % what)
+        if out[6] > cols:          # cannot happen: no strategy grows the grid (see the module docstring)
+            raise NotImplementedError('%s grid grew from %d to %d columns' % (what, cols, out[6]))
         return out
 
     def _batch(self, mapped, images, ps_1d_indices, rows, cols):
@@ -406,9 +409,8 @@ class DataLoader(object):
 
         from . import ops
 
-        if self.pm_strategy not in (0, 1):
-            raise NotImplementedError('positional_mapping_strategy %r: only 0 (skip) and 1 (shift) run on the GPU; '
-                                      'strategy 2 (grid expansion) is out of scope' % (self.pm_strategy,))
+        if self.pm_strategy not in (0, 1, 2):
+            raise ValueError('positional_mapping_strategy %r: 0 (skip), 1 (shift) or 2 (expand)' % (self.pm_strategy,))
         dev = torch.device(self.device) if self.device is not None else torch.device('cuda', torch.cuda.current_device())
         tok_box, tok_id, tok_ecid, tok_cls, extent, doc_off = self.pack_documents(docs, labels)
         up = lambda a: torch.from_numpy(a).to(dev, non_blocking=True)

@@ -46,7 +46,9 @@ const char* cutie_last_error(void);
 
 /* ---------------------------------------------------------------------------------------
  * K0  token -> grid positional mapping.   Replaces DataLoader._positional_mapping,
- *     data_loader_json.py:437-577 (strategies 0 and 1; bit-exact, fp64 keys, stable order).
+ *     data_loader_json.py:437-577 (bit-exact, fp64 keys, stable order).  strategy 0 = skip a token
+ *     whose row tail is full, 1 = shift the row left, 2 = the reference's "expand", whose outputs are
+ *     those of 1 on every input (its search starts on the cell the shift has just freed).
  *
  * tok_box    int32 [T,4]  x_left,y_top,x_right,y_bottom per token, documents concatenated
  * tok_id     int32 [T]    dict id (word_to_index[text], :469)

@@ -247,11 +247,30 @@ def test_prefetch_keeps_order_passes_errors_and_stops():
     assert not it._t.is_alive()
 
 
-def test_strategy2_is_refused(workdir):
+def test_unknown_mapping_strategy_is_refused(workdir):
+    ld = DataLoader(make_params(workdir, positional_mapping_strategy=3), update_dict=False,
+                    load_dictionary=True, verbose=False)
+    with pytest.raises(ValueError):
+        ld._positional_mapping(ld.training_docs, ld.training_labels, 64, 64)
+
+
+@pytest.mark.gpu
+def test_strategy2_on_gpu_matches_the_reference(workdir):
+    """the reference's default strategy: tests/golden/strategy2_cases.json holds the sha256 of what the
+    reference's own _positional_mapping returns for it"""
+    import hashlib
+    sha = lambda a: hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+    cases = {c["name"]: c for c in _load("strategy2_cases.json")["cases"]}
     ld = DataLoader(make_params(workdir, positional_mapping_strategy=2), update_dict=False,
                     load_dictionary=True, verbose=False)
-    with pytest.raises(NotImplementedError):
-        ld._positional_mapping(ld.training_docs, ld.training_labels, 64, 64)
+    for rows, cols in [(64, 64), (42, 63), (48, 20), (64, 8)]:
+        c = cases["faktura1_r%dc%d" % (rows, cols)]
+        out = ld._positional_mapping(ld.training_docs[:1], ld.training_labels, rows, cols)
+        assert out[6] == c["updated_cols_s2"] == cols
+        assert sha(np.stack(out[0])[..., 0].astype(np.int32)[..., None]) == c["s2_grid_sha256"]
+        assert sha(np.stack(out[1]).astype(np.int8)) == c["s2_labels_sha256"]
+        assert sha(np.stack(out[7]).astype(np.int32)) == c["s2_ps_x_sha256"]
+        assert sha(np.stack(out[8]).astype(np.int32)) == c["s2_ps_y_sha256"]
 
 
 def test_dictionary_round_trip(workdir, tmp_path):

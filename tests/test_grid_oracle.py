@@ -89,6 +89,34 @@ def test_synthetic_cases(golden_dir):
             assert bm == {int(k): v for k, v in case["bbox_mapids"][d].items()}, name
 
 
+def test_strategy2_restatement_matches_the_reference(faktura, golden_dir):
+    """tests/golden/strategy2_cases.json: the reference's strategy-2 outputs (sha256) and its own verdict
+    that they equal strategy 1's on every fixture document; the oracle restates :541-550 literally."""
+    items, _, _ = faktura
+    with open(os.path.join(golden_dir, "strategy2_cases.json")) as f:
+        cases = {c["name"]: c for c in json.load(f)["cases"]}
+    assert len(cases) == 15 and all(c["identical_to_s1"] for c in cases.values())
+    doc = items["docs"]["training"][0]
+    for name, c in cases.items():
+        if not name.startswith("faktura1_"):
+            continue
+        o = go.positional_mapping([doc], c["rows"], c["cols"], 2, items["num_classes"])[0]
+        assert o["cols_out"] == c["updated_cols_s2"] == c["cols"]
+        assert _sha(o["grid"][None, ..., None].astype(np.int32)) == c["s2_grid_sha256"], name
+        assert _sha(o["labels"][None].astype(np.int8)) == c["s2_labels_sha256"], name
+        assert _sha(o["ps_x"][None].astype(np.int32)) == c["s2_ps_x_sha256"], name
+        assert _sha(o["ps_y"][None].astype(np.int32)) == c["s2_ps_y_sha256"], name
+    with open(os.path.join(golden_dir, "synthetic_grids.json")) as f:
+        meta = json.load(f)
+    for case in meta["cases"]:
+        c = cases["synthetic_" + case["name"]]
+        outs = go.positional_mapping(case["docs"], case["rows"], case["cols"], 2, meta["num_classes"])
+        assert all(o["cols_out"] == case["cols"] for o in outs)
+        assert _sha(np.stack([o["grid"] for o in outs])[..., None].astype(np.int32)) == c["s2_grid_sha256"], case["name"]
+        assert _sha(np.stack([o["labels"] for o in outs]).astype(np.int8)) == c["s2_labels_sha256"], case["name"]
+        assert _sha(np.stack([o["ps_x"] for o in outs]).astype(np.int32)) == c["s2_ps_x_sha256"], case["name"]
+
+
 def test_label_overflow_present_in_fixture(golden_dir):
     """a second entity of one class gives labels >= num_classes."""
     npz = np.load(os.path.join(golden_dir, "synthetic_grids.npz"))
