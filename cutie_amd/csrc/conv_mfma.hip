@@ -650,6 +650,31 @@ __global__ __launch_bounds__(WG5_NT, 2) void wgrad5_kernel(Wgrad5Params p) {
 
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slabs, int splits, long long n,
                                                            float* __restrict__ dw, int accumulate) {
+    // n is a multiple of 4 whenever cout is (every layer but the 18-class logits): 16-byte lanes, four
+    // slabs in flight per lane; the summation order over the slabs is fixed either way
+    if ((n & 3) == 0 && ((reinterpret_cast<uintptr_t>(slabs) | reinterpret_cast<uintptr_t>(dw)) & 15) == 0) {
+        const long long n4 = n >> 2;
+        const float4* __restrict__ s4 = reinterpret_cast<const float4*>(slabs);
+        float4* __restrict__ d4 = reinterpret_cast<float4*>(dw);
+        for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+            float4 s = accumulate ? d4[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+            int k = 0;
+            for (; k + 4 <= splits; k += 4) {
+                const float4 a = s4[(long long)k * n4 + i], b = s4[(long long)(k + 1) * n4 + i];
+                const float4 c = s4[(long long)(k + 2) * n4 + i], d = s4[(long long)(k + 3) * n4 + i];
+                s.x += a.x; s.y += a.y; s.z += a.z; s.w += a.w;
+                s.x += b.x; s.y += b.y; s.z += b.z; s.w += b.w;
+                s.x += c.x; s.y += c.y; s.z += c.z; s.w += c.w;
+                s.x += d.x; s.y += d.y; s.z += d.z; s.w += d.w;
+            }
+            for (; k < splits; ++k) {
+                const float4 a = s4[(long long)k * n4 + i];
+                s.x += a.x; s.y += a.y; s.z += a.z; s.w += a.w;
+            }
+            d4[i] = s;
+        }
+        return;
+    }
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
         float s = accumulate ? dw[i] : 0.f;
         for (int k = 0; k < splits; ++k) s += slabs[(long long)k * n + i];
@@ -804,7 +829,7 @@ extern "C" int cutie_conv_wgrad(const void* x, int ld_x, int cin, const void* dz
         return CUTIE_E_WORKSPACE;
     }
     const long long n_w = (long long)kh * kw * cin * cout;
-    long long g_red = cutie::cdiv(n_w, 256);
+    long long g_red = cutie::cdiv((n_w & 3) == 0 ? n_w / 4 : n_w, 256);
     if (g_red > 4096) g_red = 4096;
     if (dtype != CUTIE_F32 && kw <= WG5_KW && (long long)B * H * W * (ld_x > ld_dz ? ld_x : ld_dz) * es < (1ll << 31)) {
         Wgrad5Params q;
@@ -881,7 +906,7 @@ extern "C" int cutie_conv_wgrad(const void* x, int ld_x, int cin, const void* dz
     }
     CUTIE_CHECK_LAUNCH();
     const long long n = (long long)kh * kw * cin * cout;
-    long long g = cutie::cdiv(n, 256);
+    long long g = cutie::cdiv((n & 3) == 0 ? n / 4 : n, 256);
     if (g > 4096) g = 4096;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)g), dim3(256), 0, stream, (const float*)workspace, p.splits, n,
                        dw, accumulate);
