@@ -359,3 +359,68 @@ def test_prefetched_batches_feed_the_train_step(workdir):
         losses.append(out["total_loss"])
     it.close()
     assert len(losses) == 6 and all(np.isfinite(l) for l in losses) and losses[-1] < losses[0]
+
+
+# ------------------------------------------------------------------ a14: CUTIE2 image input + sampler indices
+def _synthetic_image(path):
+    import re
+    m = re.search(r"_(\d+)x(\d+)\.jpg$", path)
+    if not m:
+        return None
+    h, w = int(m.group(1)), int(m.group(2))
+    yy, xx = np.meshgrid(np.arange(h), np.arange(w), indexing="ij")
+    return np.stack([(yy * 3 + xx) % 256, (yy + 2 * xx) % 256, (yy * xx) % 256], axis=-1).astype(np.uint8)
+
+
+def test_positional_sampling_indices_match_reference(workdir):
+    """ps_1d, shapes and padding of DataLoader._positional_sampling against the reference's own function
+    (tests/golden/positional_sampling_cases.json, made by make_golden_sampling.py with an injected image
+    reader: the integer half is pinned, pixel values are not - cv2 is absent on both sides)."""
+    ld = DataLoader(make_params(workdir, image_reader=_synthetic_image), update_dict=False, load_dictionary=True,
+                    verbose=False)
+    cases = _load("positional_sampling_cases.json")["cases"]
+    assert len(cases) == 5
+    for c in cases:
+        psx = [np.array(a, dtype=np.int32) for a in c["ps_x"]]
+        psy = [np.array(a, dtype=np.int32) for a in c["ps_y"]]
+        images, ps_1d = ld._positional_sampling("imgs", c["file_names"], psx, psy, c["cols"])
+        assert len(images) == len(ps_1d) == c["n_returned"], c["name"]
+        assert [list(im.shape) for im in images] == c["image_shapes"], c["name"]
+        for got, ref in zip(ps_1d, c["ps_1d"]):
+            assert got.dtype == np.int32 and got.tolist() == ref, c["name"]
+        for im in images:
+            assert im.min() >= -0.5 and im.max() <= 0.5          # (x - 127.5) / 255 (:607)
+    # the missing image ends the batch early, as the reference's `break` does (:608-612)
+    assert [c["n_returned"] for c in cases if c["name"] == "missing_second"] == [1]
+
+
+def test_positional_sampling_needs_a_reader(workdir):
+    ld = DataLoader(make_params(workdir), update_dict=False, load_dictionary=True, verbose=False)
+    with pytest.raises(NotImplementedError):
+        ld._positional_sampling("imgs", ["a_10x10.jpg"], [np.zeros((4, 4))], [np.zeros((4, 4))], 4)
+
+
+@pytest.mark.gpu
+def test_cutie2_batches_train_end_to_end(workdir):
+    """use_cutie2 loader -> data_image / ps_1d_indices -> CUTIE2 train step (config 4 / 5 plumbing)"""
+    import types
+    from cutie_amd.model_cutie2_aspp import CUTIE2
+    from cutie_amd.runtime import Engine
+    from cutie_amd.train import Trainer
+    reader = lambda path: _synthetic_image("x_1000x800.jpg")
+    ld = DataLoader(make_params(workdir, batch_size=1, use_cutie2=True, image_reader=reader), update_dict=False,
+                    load_dictionary=True, verbose=False)
+    random.seed(5)
+    b = ld.next_batch()
+    rows, cols = b["shape"]
+    assert b["data_image"].shape[0] == 1 and b["data_image"].shape[2] == cols and b["data_image"].shape[3] == 3
+    assert b["ps_1d_indices"].shape == (1, rows * cols)
+    assert int(b["ps_1d_indices"].max()) <= cols * b["data_image"].shape[1] - 2
+    p = types.SimpleNamespace(embedding_size=128, weight_decay=5e-4, hard_negative_ratio=3, batch_size=1)
+    net = CUTIE2(20000, ld.num_classes, p)
+    net.build_loss()
+    tr = Trainer(Engine(net, "cuda:0", dtype="f16", seed=0), learning_rate=1e-3)
+    losses = [tr.step({"grid_table": b["device"]["grid_table"], "gt_classes": b["device"]["gt_classes"],
+                       "data_image": b["data_image"], "ps_1d_indices": b["ps_1d_indices"]})["total_loss"]
+              for _ in range(5)]
+    assert all(np.isfinite(l) for l in losses) and losses[-1] < losses[0]
