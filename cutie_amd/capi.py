@@ -66,7 +66,9 @@ SIGNATURES = {
     "cutie_softmax_ce_fwd": (_i, [_vp, _i, _i, _vp, _i64, _i, _vp, _vp, _vp, _vp]),
     "cutie_hnm_workspace_bytes": (_sz, [_i64]),
     "cutie_hnm_weights": (_i, [_vp, _vp, _i64, _i, _vp, _vp, _vp, _sz, _vp]),
-    "cutie_softmax_ce_bwd": (_i, [_vp, _vp, _vp, _i64, _i, _vp, _i, _i, _vp, _vp]),
+    "cutie_softmax_ce_bwd": (_i, [_vp, _vp, _vp, _i64, _i, _vp, _i, _i, _vp, _vp, _vp]),
+    "cutie_ghm_state_bytes": (_sz, [_i]),
+    "cutie_ghm_weights": (_i, [_vp, _i, _i, _vp, _i64, _i, _i, _f, _f, _vp, _sz, _vp, _vp, _vp]),
     "cutie_l2_add": (_i, [_vp, _vp, _i64, _f, _vp, _vp, _vp, _vp]),
     "cutie_sumsq": (_i, [_vp, _i64, _i, _vp, _vp, _vp, _vp]),
     "cutie_loss_scale_init": (_i, [_vp, _f, _vp]),

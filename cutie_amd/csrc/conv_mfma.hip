@@ -236,7 +236,8 @@ __global__ __launch_bounds__(CONV_NT, 2) void conv_kernel(ConvParams p) {
             for (int r = 0; r < 4; ++r) {
                 const int w = w0 + (mb % TWB) * 16 + lg * 4 + r;
                 float v = acc[m][n][r] + bv;
-                if (p.relu) v = fmaxf(v, 0.f);
+                if (p.relu == 1) v = fmaxf(v, 0.f);
+                else if (p.relu == 2) v = 1.f / (1.f + expf(-v));
                 if (!(h < H && w < W)) v = 0.f;
                 s1 += v;
                 s2 += v * v;
@@ -722,6 +723,7 @@ extern "C" int cutie_conv_fwd(const cutie_conv_seg* segs, int n_segs, int B, int
     CUTIE_CHECK_ARG(dtype == CUTIE_F32 || dtype == CUTIE_BF16 || dtype == CUTIE_F16, "conv_fwd: dtype %d", dtype);
     CUTIE_CHECK_ARG(out_dtype == CUTIE_F32 || out_dtype == dtype || (dtype == CUTIE_F32 && (out_dtype == CUTIE_BF16 || out_dtype == CUTIE_F16)),
                     "conv_fwd: out_dtype %d must be f32 or the input dtype %d", out_dtype, dtype);
+    CUTIE_CHECK_ARG(relu >= 0 && relu <= 2, "conv_fwd: activation code %d (0 none, 1 ReLU, 2 sigmoid)", relu);
     if (B == 0) return CUTIE_OK;
     CUTIE_CHECK_ARG(out, "conv_fwd: null output");
     const int es = dtype == CUTIE_F32 ? 4 : 2;

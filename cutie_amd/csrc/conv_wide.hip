@@ -283,7 +283,7 @@ __global__ __launch_bounds__(CW_NT) void conv_wide_kernel(ConvParams p) {
 
 // channel tile for n_out: 256 where it divides, else 128, else 64; 0 = not a wide-kernel shape
 int conv_wide_tile(const ConvParams& p) {
-    if ((p.ld_out * 2) % 16 != 0 || !aligned16(p.out)) return 0;
+    if ((p.ld_out * 2) % 16 != 0 || !aligned16(p.out) || p.relu == 2) return 0;    // sigmoid: generic kernel only
     for (int s = 0; s < p.nseg; ++s)
         if (p.seg[s].cin % 64 != 0 || p.seg[s].kh * p.seg[s].kw > 32) return 0;
     if (p.n_out % 256 == 0) return 256;

@@ -66,7 +66,8 @@ __global__ __launch_bounds__(256) void softmax_ce_bwd_kernel(const float* __rest
                                                              const int32_t* __restrict__ labels,
                                                              const float* __restrict__ weight, int64_t n_cells,
                                                              int C, TD* __restrict__ dlogits, int ld,
-                                                             const float* __restrict__ loss_scale) {
+                                                             const float* __restrict__ loss_scale,
+                                                             const float* __restrict__ elem_weight) {
     const float ls = loss_scale ? loss_scale[0] : 1.f;
     const int64_t total = n_cells * C;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
@@ -74,7 +75,8 @@ __global__ __launch_bounds__(256) void softmax_ce_bwd_kernel(const float* __rest
         const int64_t n = i / C;
         const int c = (int)(i - n * C);
         const float w = weight[n];
-        const float g = ls * w * (probs[i] - (labels[n] == c ? 1.f : 0.f));
+        float g = ls * w * (probs[i] - (labels[n] == c ? 1.f : 0.f));
+        if (elem_weight) g *= elem_weight[i];      // GHM: the CE saw logits * elem_weight
         store_from_f32(dlogits + n * ld + c, w == 0.f ? 0.f : g);
     }
 }
@@ -362,7 +364,116 @@ __global__ __launch_bounds__(64) void hnm_final_kernel(int chunks, int ratio, vo
     loss_out[2] = (float)num_bg;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Gradient harmonising weights, calc_ghm_weights of main_train_json.py:86-119 (use_ghm = 1).
+//   grad = |logit - onehot| per (cell, class) in double (numpy promotes float32 - int64 to float64);
+//   bin i holds edges[i] <= grad < edges[i+1], edges[i] = i / bins, the last edge + eps;
+//   acc_sum[i] = momentum * acc_sum[i] + (1 - momentum) * count[i] for the non-empty bins (M of them);
+//   weight = N / acc_sum[bin] / M inside a bin, 1 / M outside every bin (grad >= 1 + eps), N = cells * C.
+// The histogram runs on the whole grid, the M-bin update on one lane, the weights (and the weighted
+// logits the loss is taken of, model_cutie.py:110) on the whole grid again.  State stays on the device.
+constexpr int GHM_MAX_BINS = 256;
+
+__device__ __forceinline__ int ghm_bin(float logit, bool hot, int bins, double eps) {
+    const double g = fabs((double)logit - (hot ? 1.0 : 0.0));
+    int i = (int)(g * bins);
+    if (i > bins - 1) i = bins - 1;
+    while (i > 0 && g < (double)i / bins) --i;
+    while (i < bins - 1 && g >= (double)(i + 1) / bins) ++i;
+    const double hi = (i == bins - 1) ? (double)bins / bins + eps : (double)(i + 1) / bins;
+    return (g >= (double)i / bins && g < hi) ? i : bins;     // `bins` = outside every bin
+}
+
+template <typename TL>
+__global__ __launch_bounds__(256) void ghm_hist_kernel(const TL* __restrict__ logits, int ld,
+                                                       const int32_t* __restrict__ labels, int64_t n_cells, int C,
+                                                       int bins, double eps, unsigned* __restrict__ counts) {
+    __shared__ unsigned h[GHM_MAX_BINS + 1];
+    for (int i = threadIdx.x; i <= bins; i += 256) h[i] = 0u;
+    __syncthreads();
+    const int64_t total = n_cells * C;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t n = i / C;
+        const int c = (int)(i - n * C);
+        atomicAdd(&h[ghm_bin(load_as_f32(logits + n * ld + c), labels[n] == c, bins, eps)], 1u);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < bins; i += 256)
+        if (h[i]) atomicAdd(counts + i, h[i]);
+}
+
+__global__ void ghm_update_kernel(const unsigned* __restrict__ counts, int bins, double momentum, double n_total,
+                                  double* __restrict__ acc_sum, float* __restrict__ table) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    int m = 0;
+    for (int i = 0; i < bins; ++i) {
+        if (counts[i] > 0u) {
+            acc_sum[i] = momentum * acc_sum[i] + (1.0 - momentum) * (double)counts[i];
+            ++m;
+        }
+    }
+    const double div = m > 0 ? (double)m : 1.0;
+    for (int i = 0; i < bins; ++i) table[i] = (float)((counts[i] > 0u ? n_total / acc_sum[i] : 1.0) / div);
+    table[bins] = (float)(1.0 / div);
+}
+
+template <typename TL>
+__global__ __launch_bounds__(256) void ghm_apply_kernel(const TL* __restrict__ logits, int ld,
+                                                        const int32_t* __restrict__ labels, int64_t n_cells, int C,
+                                                        int bins, double eps, const float* __restrict__ table,
+                                                        float* __restrict__ weights, float* __restrict__ weighted) {
+    const int64_t total = n_cells * C;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t n = i / C;
+        const int c = (int)(i - n * C);
+        const float x = load_as_f32(logits + n * ld + c);
+        const float w = table[ghm_bin(x, labels[n] == c, bins, eps)];
+        weights[i] = w;
+        if (weighted) weighted[i] = x * w;
+    }
+}
+
 }  // namespace
+
+extern "C" size_t cutie_ghm_state_bytes(int bins) {
+    if (bins < 1 || bins > GHM_MAX_BINS) return 0;
+    return (size_t)bins * sizeof(double) + (size_t)(bins + 1) * sizeof(float) + (size_t)bins * sizeof(unsigned) + 16;
+}
+
+extern "C" int cutie_ghm_weights(const void* logits, int ld, int dtype, const int32_t* labels, int64_t n_cells, int C,
+                                 int bins, float momentum, float eps, void* state, size_t state_bytes, float* weights,
+                                 float* weighted_logits, cutie_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    CUTIE_CHECK_ARG(n_cells >= 0 && C >= 1 && ld >= C, "ghm_weights: n=%lld C=%d ld=%d", (long long)n_cells, C, ld);
+    CUTIE_CHECK_ARG(bins >= 1 && bins <= GHM_MAX_BINS, "ghm_weights: bins=%d (1..%d)", bins, GHM_MAX_BINS);
+    CUTIE_CHECK_ARG(momentum >= 0.f && momentum < 1.f, "ghm_weights: momentum %g", (double)momentum);
+    if (!state || state_bytes < cutie_ghm_state_bytes(bins) || (reinterpret_cast<uintptr_t>(state) & 7)) {
+        cutie::set_error("ghm_weights: state %zu < %zu bytes (or not 8-byte aligned)", state_bytes, cutie_ghm_state_bytes(bins));
+        return CUTIE_E_WORKSPACE;
+    }
+    if (n_cells == 0) return CUTIE_OK;
+    CUTIE_CHECK_ARG(logits && labels && weights, "ghm_weights: null pointer");
+    double* acc_sum = reinterpret_cast<double*>(state);
+    float* table = reinterpret_cast<float*>(acc_sum + bins);
+    unsigned* counts = reinterpret_cast<unsigned*>(table + bins + 1);
+    CUTIE_CHECK_HIP(hipMemsetAsync(counts, 0, (size_t)bins * sizeof(unsigned), stream));
+    int64_t g = cutie::cdiv(n_cells * C, 256 * 8);
+    if (g > 1024) g = 1024;
+    if (g < 1) g = 1;
+    CUTIE_DISPATCH_DTYPE(dtype, DT,
+        hipLaunchKernelGGL(ghm_hist_kernel<typename elem<DT>::type>, dim3((int)g), dim3(256), 0, stream,
+                           (const typename elem<DT>::type*)logits, ld, labels, n_cells, C, bins, (double)eps, counts));
+    CUTIE_CHECK_LAUNCH();
+    hipLaunchKernelGGL(ghm_update_kernel, dim3(1), dim3(64), 0, stream, (const unsigned*)counts, bins, (double)momentum,
+                       (double)n_cells * C, acc_sum, table);
+    CUTIE_CHECK_LAUNCH();
+    CUTIE_DISPATCH_DTYPE(dtype, DT,
+        hipLaunchKernelGGL(ghm_apply_kernel<typename elem<DT>::type>, dim3((int)g), dim3(256), 0, stream,
+                           (const typename elem<DT>::type*)logits, ld, labels, n_cells, C, bins, (double)eps,
+                           (const float*)table, weights, weighted_logits));
+    CUTIE_CHECK_LAUNCH();
+    return CUTIE_OK;
+}
 
 extern "C" int cutie_softmax_ce_fwd(const void* logits, int ld, int dtype, const int32_t* labels, int64_t n_cells,
                                     int C, float* ce, float* probs, int32_t* bad_labels, cutie_stream_t stream_) {
@@ -413,7 +524,7 @@ extern "C" int cutie_hnm_weights(const float* ce, const int32_t* labels, int64_t
 
 extern "C" int cutie_softmax_ce_bwd(const float* probs, const int32_t* labels, const float* weight, int64_t n_cells,
                                     int C, void* dlogits, int ld, int dtype, const float* loss_scale,
-                                    cutie_stream_t stream_) {
+                                    const float* elem_weight, cutie_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     CUTIE_CHECK_ARG(n_cells >= 0 && C >= 1 && ld >= C, "softmax_ce_bwd: n=%lld C=%d ld=%d", (long long)n_cells, C, ld);
     if (n_cells == 0) return CUTIE_OK;
@@ -422,7 +533,7 @@ extern "C" int cutie_softmax_ce_bwd(const float* probs, const int32_t* labels, c
     if (g > 2048) g = 2048;
     CUTIE_DISPATCH_DTYPE(dtype, DT,
         hipLaunchKernelGGL(softmax_ce_bwd_kernel<typename elem<DT>::type>, dim3((int)g), dim3(256), 0, stream, probs,
-                           labels, weight, n_cells, C, (typename elem<DT>::type*)dlogits, ld, loss_scale));
+                           labels, weight, n_cells, C, (typename elem<DT>::type*)dlogits, ld, loss_scale, elem_weight));
     CUTIE_CHECK_LAUNCH();
     return CUTIE_OK;
 }

@@ -213,7 +213,11 @@ __global__ __launch_bounds__(256) void in_bwd_apply_kernel(const TD* __restrict_
             for (int e = 0; e < VEC; ++e) {
                 const float xh = (x.v[e] - mean[e]) * inv[e];
                 float d = inv[e] * (g.v[e] - m1[e] - xh * m2[e]);
-                if (relu && !(x.v[e] > 0.f)) d = 0.f;
+                if (relu == 1) {
+                    if (!(x.v[e] > 0.f)) d = 0.f;
+                } else if (relu == 2) {
+                    d *= x.v[e] * (1.f - x.v[e]);      // sigmoid': a is the stored sigmoid output
+                }
                 o.v[e] = d;
                 sb[e] += d;
             }

@@ -48,9 +48,10 @@ class CUTIE(Model):
         self.loss_logits_name = "cls_logits"
         self.loss_spec = {"labels": "gt_classes", "logits": "cls_logits",
                           "hard_negative_ratio": self.hard_negative_ratio, "weight_decay": self.weight_decay}
-        if self.use_ghm:
-            raise NotImplementedError("use_ghm=1 (sigmoid logits + GHM weights, main_train_json.py:86-119) "
-                                      "is listed as 'next' (SURVEY.md 8f4), not built")
+        # use_ghm = 1 (main_train_json.py:65-67,86-119): the logits layer ends in a sigmoid and the loss is
+        # taken of cls_logits * ghm_weights; the weights are computed on the device from the logits
+        self.loss_spec.update({"use_ghm": self.use_ghm, "ghm_bins": int(_hp(params, "ghm_bins", 30)),
+                               "ghm_momentum": float(_hp(params, "ghm_momentum", 0)), "ghm_eps": float(_hp(params, "eps", 1e-6))})
 
     def setup(self):
         raise NotImplementedError("the max-pool / up-conv CUTIE_benchmark network (model_cutie.py:32-66) is "
@@ -64,8 +65,8 @@ class CUTIE(Model):
         self.get_output("gt_classes")
         logits = self.get_output("cls_logits")
         softmax_logits = self.get_output("softmax")
-        self.loss_spec = {"labels": "gt_classes", "logits": "cls_logits",
-                          "hard_negative_ratio": self.hard_negative_ratio, "weight_decay": self.weight_decay}
+        self.loss_spec.update({"labels": "gt_classes", "logits": "cls_logits",
+                               "hard_negative_ratio": self.hard_negative_ratio, "weight_decay": self.weight_decay})
         model_loss = Fetch("model_loss")
         regularization_loss = Fetch("regularization_loss")
         total_loss = Fetch("total_loss")

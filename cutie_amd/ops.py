@@ -123,6 +123,9 @@ def replay_sum_rows(batches, B, accumulate=False):
         call("cutie_sum_rows_batched", arr, len(arr), B, 1 if accumulate else 0, stream())
 
 
+ACTIVATION_CODE = {None: 0, False: 0, "none": 0, True: 1, "relu": 1, "sigmoid": 2}
+
+
 def conv_fwd(segs, out, n_out, bias=None, relu=False, stats=None):
     """segs: list of dict(x=[B,H,W,>=cin] view, w=packed [taps, n_rows, cin], cin, kh, kw, dil, flip,
     n_off=row offset into w).  out: [B,H,W,>=n_out] view."""
@@ -152,7 +155,7 @@ def conv_fwd(segs, out, n_out, bias=None, relu=False, stats=None):
         arr[i].kh, arr[i].kw, arr[i].dil = s["kh"], s["kw"], s["dil"]
         arr[i].flip = 1 if s.get("flip") else 0
     call("cutie_conv_fwd", arr, len(segs), B, H, W, n_out, ptr(out), ld_of(out), dt_of(out), ptr(bias),
-         1 if relu else 0, ptr(stats), dt, stream())
+         ACTIVATION_CODE[relu], ptr(stats), dt, stream())
     return out
 
 
@@ -197,7 +200,7 @@ def in_bwd_apply(dy, a, stats, red, dz, dbias_part=None, relu=True, eps=IN_EPS):
     """dbias_part: f32 [B, C] zeroed partial sums (fold with sum_rows)."""
     B, HW, C = _bhwc(a)
     call("cutie_in_bwd_apply", ptr(dy), ld_of(dy), dt_of(dy), ptr(a), ld_of(a), dt_of(a), ptr(stats), eps,
-         ptr(red), 1 if relu else 0, ptr(dz), ld_of(dz), dt_of(dz), ptr(dbias_part), B, HW, C, stream())
+         ptr(red), ACTIVATION_CODE[relu], ptr(dz), ld_of(dz), dt_of(dz), ptr(dbias_part), B, HW, C, stream())
     return dz
 
 
@@ -236,9 +239,24 @@ def hnm_weights(ce, labels, ratio, weight, loss_out, workspace=None):
          ptr(workspace), workspace.numel(), stream())
 
 
-def softmax_ce_bwd(probs, labels, weight, C, dlogits, loss_scale=None):
+def softmax_ce_bwd(probs, labels, weight, C, dlogits, loss_scale=None, elem_weight=None):
     call("cutie_softmax_ce_bwd", ptr(probs), ptr(labels), ptr(weight), labels.numel(), C, ptr(dlogits),
-         ld_of(dlogits), dt_of(dlogits), ptr(loss_scale), stream())
+         ld_of(dlogits), dt_of(dlogits), ptr(loss_scale), ptr(elem_weight), stream())
+
+
+def ghm_state(bins, device):
+    """zeroed device state for ghm_weights (acc_sum carries over between steps)"""
+    n = capi.lib().cutie_ghm_state_bytes(int(bins))
+    if n == 0:
+        raise capi.CutieError("ghm_bins=%r is outside 1..256" % (bins,))
+    return torch.zeros((n + 7) // 8, dtype=torch.int64, device=device)
+
+
+def ghm_weights(logits, labels, C, bins, momentum, eps, state, weights, weighted_logits=None):
+    """logits [..., >=C] view; labels int32; weights / weighted_logits f32 [N, C] contiguous"""
+    call("cutie_ghm_weights", ptr(logits), ld_of(logits), dt_of(logits), ptr(labels), labels.numel(), C, int(bins),
+         float(momentum), float(eps), ptr(state), state.numel() * state.element_size(), ptr(weights),
+         ptr(weighted_logits), stream())
 
 
 # ------------------------------------------------------------------------------------ K12, K14

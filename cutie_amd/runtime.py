@@ -325,8 +325,8 @@ class Engine(object):
                 cin_pad = _pad(a["cin"], self.bke)
                 ops.conv_fwd([dict(x=P.view(src.name, cin_pad), w=self.w_fwd[n.name + "/weights"], cin=cin_pad,
                                    kh=a["kh"], kw=a["kw"], dil=a["rate"])],
-                             P.a[n.name], n.channels, bias=self.params[n.name + "/biases"], relu=True,
-                             stats=P.stats[n.name])
+                             P.a[n.name], n.channels, bias=self.params[n.name + "/biases"],
+                             relu=a.get("activation", "relu"), stats=P.stats[n.name])
                 ops.in_apply(P.a[n.name][..., :n.channels], P.stats[n.name], P.view(n.name, n.channels))
             elif n.op == "global_pool":
                 src = n.inputs[0]
@@ -383,9 +383,25 @@ class Engine(object):
         net, spec = self.net, self.net.loss_spec
         lname = net.loss_logits_name
         C = self.C
-        ops.hnm_weights(P.ce, P.labels, int(spec["hard_negative_ratio"]), P.weight, P.loss, P.hnm_ws)
         ls = self.loss_scale
-        ops.softmax_ce_bwd(P.probs, P.labels, P.weight, C, P.dy[lname][..., :C], ls)
+        if spec.get("use_ghm"):
+            # model_cutie.py:110: the CE is taken of cls_logits * ghm_weights; the weights are a constant
+            # input computed from this very forward pass (the reference's two partial_run phases)
+            if getattr(self, "ghm_state", None) is None:
+                self.ghm_state = ops.ghm_state(spec["ghm_bins"], self.dev)
+            if getattr(P, "ghm_w", None) is None:
+                P.ghm_w = torch.zeros((P.N, C), dtype=torch.float32, device=self.dev)
+                P.ghm_z = torch.zeros((P.N, C), dtype=torch.float32, device=self.dev)
+                P.ghm_probs = torch.zeros((P.N, C), dtype=torch.float32, device=self.dev)
+            ops.ghm_weights(P.view(lname, C), P.labels, C, spec["ghm_bins"], spec["ghm_momentum"], spec["ghm_eps"],
+                            self.ghm_state, P.ghm_w, P.ghm_z)
+            P.bad.zero_()
+            ops.softmax_ce_fwd(P.ghm_z, P.labels, C, P.ce, P.ghm_probs, P.bad)
+            ops.hnm_weights(P.ce, P.labels, int(spec["hard_negative_ratio"]), P.weight, P.loss, P.hnm_ws)
+            ops.softmax_ce_bwd(P.ghm_probs, P.labels, P.weight, C, P.dy[lname][..., :C], ls, P.ghm_w)
+        else:
+            ops.hnm_weights(P.ce, P.labels, int(spec["hard_negative_ratio"]), P.weight, P.loss, P.hnm_ws)
+            ops.softmax_ce_bwd(P.probs, P.labels, P.weight, C, P.dy[lname][..., :C], ls)
         self.grads_flat.zero_()
         P.red_all.zero_()
         P.reg.zero_()
@@ -399,7 +415,7 @@ class Engine(object):
                 av = P.a[n.name][..., :n.channels]
                 ops.in_bwd_stats(dy, av, P.stats[n.name], P.red[n.name])
                 ops.in_bwd_apply(dy, av, P.stats[n.name], P.red[n.name], P.dz[n.name][..., :n.channels],
-                                 dbias_part=P.dbpart[n.name], relu=True)
+                                 dbias_part=P.dbpart[n.name], relu=a.get("activation", "relu"))
                 src = n.inputs[0]
                 ops.conv_wgrad(P.view(src.name, a["cin"]), a["cin"], P.dz[n.name][..., :n.channels], n.channels,
                                a["kh"], a["kw"], a["rate"], self.grads[n.name + "/weights"], P.wgrad_ws)

@@ -115,6 +115,8 @@ typedef struct {
     int flip;             /* 0 forward taps, 1 negated shifts (data gradient)              */
 } cutie_conv_seg;
 
+/* relu: activation code - 0 none, 1 ReLU, 2 sigmoid (the logits layer under use_ghm,
+ * model_framework.py:173-175; generic kernel only).  The same code goes to cutie_in_bwd_apply. */
 int cutie_conv_fwd(const cutie_conv_seg* segs /* host */, int n_segs,
                    int B, int H, int W, int n_out,
                    void* out, int ld_out, int out_dtype,
@@ -156,7 +158,8 @@ int cutie_pack_weights_batched(const cutie_pack_desc* descs, int n, int dtype, c
  *   apply:     y = (a - mean) * rsqrt(var + eps)
  *   bwd_stats: red[b][c] = (sum dy, sum dy*xhat)           (caller-zeroed, f32 [B][C][2])
  *   bwd_apply: dz = [a > 0] * inv * (dy - red0/HW - xhat*red1/HW);  dbias_part[b][c] += sum_hw dz
- *              (relu != 0 applies the ReLU mask of model_framework.py:173; dbias_part f32
+ *              (relu = 1 applies the ReLU mask of model_framework.py:173, relu = 2 the sigmoid
+ *              derivative a*(1-a) of :175, 0 neither; dbias_part f32
  *              [B][C], caller-zeroed, nullable; cutie_sum_rows folds it over b into d(biases)
  *              in a fixed order)
  */
@@ -213,7 +216,24 @@ int cutie_hnm_weights(const float* ce, const int32_t* labels, int64_t n_cells, i
                       cutie_stream_t stream);
 int cutie_softmax_ce_bwd(const float* probs, const int32_t* labels, const float* weight,
                          int64_t n_cells, int C, void* dlogits, int ld, int dtype,
-                         const float* loss_scale /* nullable, see K12 */, cutie_stream_t stream);
+                         const float* loss_scale /* nullable, see K12 */,
+                         const float* elem_weight /* nullable f32 [n_cells][C]: GHM, below */,
+                         cutie_stream_t stream);
+
+/* Gradient harmonising weights (use_ghm = 1).   Replaces calc_ghm_weights, main_train_json.py:86-119,
+ * and the product cls_logits * ghm_weights of model_cutie.py:110.
+ *   grad = |logit - onehot| per (cell, class); bin i: i/bins <= grad < (i+1)/bins (last edge + eps);
+ *   acc_sum[i] = momentum*acc_sum[i] + (1-momentum)*count[i] for the M non-empty bins;
+ *   weights[n][c] = (n_cells*C) / acc_sum[bin] / M   (1/M where grad lies outside every bin);
+ *   weighted_logits[n][c] = logit * weights[n][c]   (nullable) - the tensor the CE is taken of.
+ * state: cutie_ghm_state_bytes(bins) bytes, 8-byte aligned, zeroed once by the caller; it carries
+ * acc_sum from step to step (the reference's module-level list).  Feed weighted_logits to
+ * cutie_softmax_ce_fwd and `weights` to cutie_softmax_ce_bwd as elem_weight (the weights are a
+ * constant input of the graph, no gradient flows into them).  bins <= 256. */
+size_t cutie_ghm_state_bytes(int bins);
+int cutie_ghm_weights(const void* logits, int ld, int dtype, const int32_t* labels, int64_t n_cells,
+                      int C, int bins, float momentum, float eps, void* state, size_t state_bytes,
+                      float* weights, float* weighted_logits, cutie_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------
  * K12,K14  L2 regulariser, global-norm clip and Adam over flat f32 buffers.   Replaces

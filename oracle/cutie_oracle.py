@@ -167,13 +167,46 @@ def hnm_loss(ce, labels, ratio):
     return loss, weight, n_fg, num_bg
 
 
-def build_loss(params, layers, labels, hard_negative_ratio=3, weight_decay=5e-4, cell_weights=None):
+def calc_ghm_weights(logits, labels, bins=30, momentum=0.0, eps=1e-6, acc_sum=None):
+    """main_train_json.py:86-119, vectorised but with the same arithmetic: float64 `grad`, the same
+    edge list, the same in-place momentum update of `acc_sum` (a list of `bins` floats, updated here).
+    logits [B,H,W,C] (the fetched cls_logits), labels [B,H,W] -> float64 weights [B,H,W,C]."""
+    import numpy as np
+    lg = np.asarray(logits.detach().cpu().numpy() if torch.is_tensor(logits) else logits)
+    lb = np.asarray(labels.detach().cpu().numpy() if torch.is_tensor(labels) else labels).reshape(-1).astype(np.int64)
+    shape = lg.shape
+    C = shape[-1]
+    edges = [float(x) / bins for x in range(bins + 1)]
+    edges[-1] += eps
+    if acc_sum is None:
+        acc_sum = [0.0 for _ in range(bins)]
+    onehot = np.zeros((lb.size, C), dtype=np.int64)
+    onehot[np.arange(lb.size), lb] = 1
+    grad = np.abs(lg.reshape(-1).astype(np.float32) - onehot.reshape(-1))        # float32 - int64 -> float64
+    weights = np.ones(grad.shape)
+    n_total = lg.size
+    m = 0
+    for i in range(bins):
+        idx = (grad >= edges[i]) & (grad < edges[i + 1])
+        num = int(idx.sum())
+        if num > 0:
+            acc_sum[i] = momentum * acc_sum[i] + (1 - momentum) * num
+            weights[idx] = n_total / acc_sum[i]
+            m += 1
+    if m > 0:
+        weights = weights / m
+    return torch.from_numpy(weights.reshape(shape)), acc_sum
+
+
+def build_loss(params, layers, labels, hard_negative_ratio=3, weight_decay=5e-4, cell_weights=None, ghm_weights=None):
     """(model_loss, regularization_loss, total_loss, logits, softmax) - model_cutie.py:140.
     cell_weights (optional): a fixed per-cell weight vector replacing the hard-negative
     selection (tests pass the DEVICE's selection so that a top-k boundary that falls between
     two nearly equal CE values does not masquerade as a gradient error)."""
     logits = layers["cls_logits"]
     C = logits.shape[-1]
+    if ghm_weights is not None:      # model_cutie.py:110; the weights are a fed constant (float32 placeholder)
+        logits = logits * ghm_weights.to(torch.float32).to(logits.dtype)
     ce = softmax_ce(logits.reshape(-1, C), labels.reshape(-1))
     if cell_weights is not None:
         model_loss = (cell_weights.reshape(-1).to(ce.dtype) * ce).sum()
@@ -181,17 +214,19 @@ def build_loss(params, layers, labels, hard_negative_ratio=3, weight_decay=5e-4,
         model_loss, _w, _nfg, _nbg = hnm_loss(ce, labels, hard_negative_ratio)
     reg = sum(weight_decay * 0.5 * (p ** 2).sum() for n, p in params.items()
               if n.endswith("/weights") and n != "embedding/weights")
-    return model_loss, reg, model_loss + reg, logits, layers["softmax"]
+    return model_loss, reg, model_loss + reg, layers["cls_logits"], layers["softmax"]
 
 
-def loss_and_grads(params, grid, labels, hard_negative_ratio=3, weight_decay=5e-4, masks=None, cell_weights=None):
+def loss_and_grads(params, grid, labels, hard_negative_ratio=3, weight_decay=5e-4, masks=None, cell_weights=None,
+                   activation="relu", ghm_weights=None):
+    """activation='sigmoid' + ghm_weights: the use_ghm = 1 graph (model_cutie_aspp.py:17,73; model_cutie.py:110)"""
     ps = OrderedDict((k, v.detach().clone().requires_grad_(True)) for k, v in params.items())
-    layers = aspp_forward(ps, grid, masks=masks)
+    layers = aspp_forward(ps, grid, activation=activation, masks=masks)
     for t in layers.values():
         if t.requires_grad:
             t.retain_grad()
     model_loss, reg, total, logits, sm = build_loss(ps, layers, labels, hard_negative_ratio, weight_decay,
-                                                    cell_weights)
+                                                    cell_weights, ghm_weights)
     total.backward()
     grads = OrderedDict((k, v.grad) for k, v in ps.items())
     return {"model_loss": model_loss.detach(), "reg_loss": reg.detach(), "total_loss": total.detach(),

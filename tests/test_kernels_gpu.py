@@ -673,3 +673,34 @@ def test_batch_scatter_add(ops, dt):
     for b in range(B):
         ref[b].index_add_(0, idx[b].clamp(0, n_src - 1).long(), dout[b].double())
     assert relerr(acc, ref) < 1e-5
+
+
+# ------------------------------------------------------------------------------------ GHM (use_ghm = 1)
+def test_ghm_weights_match_calc_ghm_weights(ops):
+    """cutie_ghm_weights against the restated calc_ghm_weights (main_train_json.py:86-119): bin edges hit
+    exactly, gradients beyond the last edge, momentum state carried over two calls."""
+    g = torch.Generator().manual_seed(31)
+    n, C, bins = 4000, 18, 30
+    logits = torch.randn((n, C), generator=g) * 0.8 + 0.3
+    logits[:200] = torch.randint(0, bins + 1, (200, C), generator=g).float() / bins       # on the edges (as far as f32 can be)
+    logits[200:260] = 1.0 + 1e-6                                                          # the last edge + eps
+    logits[260:300] = 2.5                                                                 # outside every bin
+    labels = torch.randint(0, C, (n,), generator=g, dtype=torch.int32)
+    pad = torch.zeros((n, C + 2))
+    pad[:, :C] = logits
+    ld = pad.to(DEV)
+    for momentum in (0.0, 0.75):
+        state = ops.ghm_state(bins, DEV)
+        acc = None
+        for step in range(2):
+            w = torch.zeros((n, C), dtype=torch.float32, device=DEV)
+            z = torch.zeros((n, C), dtype=torch.float32, device=DEV)
+            shift = 0.05 * step
+            ops.ghm_weights(ld[:, :C] + shift if step else ld[:, :C], labels.to(DEV), C, bins, momentum, 1e-6, state, w, z)
+            ref, acc = co.calc_ghm_weights((logits + shift if step else logits).reshape(1, 1, n, C), labels.reshape(1, 1, n),
+                                           bins, momentum, 1e-6, acc)
+            ref = ref.reshape(n, C).float()
+            assert torch.equal(w.cpu(), ref), (momentum, step, float((w.cpu() - ref).abs().max()))
+            assert torch.equal(z.cpu(), (logits + shift if step else logits) * ref)
+    with pytest.raises(Exception):
+        ops.ghm_state(300, DEV)

@@ -311,3 +311,52 @@ def test_cutie2_backward_parity(variant, B, H, W, Hi, dtype):
     tr = Trainer(eng, learning_rate=1e-4)
     out = tr.step({"grid_table": grid.unsqueeze(-1), "gt_classes": labels, "data_image": image, "ps_1d_indices": ps})
     assert np.isfinite(out["total_loss"]) and np.isfinite(out["global_norm"]) and out["global_norm"] > 0
+
+
+# ------------------------------------------------------------------------------ use_ghm = 1
+def test_cutie_aspp_ghm_loss_and_gradients(oracle_run):
+    """sigmoid logits layer + gradient-harmonised loss (model_cutie_aspp.py:17,73; model_cutie.py:110;
+    main_train_json.py:86-119,249-254) against the oracle, f32.  The weights are a fed constant in the
+    reference's graph: the gradient check feeds the oracle the device's weights (and ReLU pattern and
+    hard-negative selection), the weights themselves are checked against calc_ghm_weights restated."""
+    from cutie_amd.model_cutie_aspp import CUTIERes
+    from cutie_amd.runtime import Engine
+    from cutie_amd.train import Trainer
+    r = oracle_run
+    pn = params_ns()
+    pn.use_ghm, pn.ghm_bins, pn.ghm_momentum, pn.eps = 1, 30, 0, 1e-6
+    net = CUTIERes(V, C, pn)
+    net.build_loss()
+    assert net.activation == "sigmoid" and net.layers["cls_logits"].attrs["activation"] == "sigmoid"
+    eng = Engine(net, DEV, dtype="f32")
+    eng.load_params(r["params"])
+    P = eng.forward(r["grid"].unsqueeze(-1), labels=r["labels"])
+    L = co.aspp_forward(r["params"], r["grid"], activation="sigmoid")
+    # sigmoid of a ~1e-2 pre-activation is 0.5 + ~2e-3: f32 holds that signal to ~3e-5 of its spread before the
+    # instance norm rescales it to unit variance - an f32 limit of the reference graph itself (measured 1.4e-4)
+    assert rel(eng.get(P, "decoder1_1"), L["decoder1_1"]) < 1e-4
+    assert rel(eng.get(P, "cls_logits"), L["cls_logits"]) < 5e-4
+    assert rel(eng.get(P, "softmax"), L["softmax"]) < 5e-4             # of the UNweighted logits (model_cutie.py:138)
+    eng.loss_backward(P)
+    torch.cuda.synchronize()
+    w_ref, _ = co.calc_ghm_weights(L["cls_logits"].float(), r["labels"], 30, 0, 1e-6)
+    w_dev = P.ghm_w.reshape(w_ref.shape).cpu().double()
+    # one element changing bins moves that bin's count, hence the weight of everything in it, by ~1e-3:
+    # "another bin" is a weight that is off by more than the count noise
+    differ = float(((w_dev - w_ref).abs() > 2e-2 * w_ref.abs()).double().mean())
+    print("GHM weights: share of elements in another bin than the f64 oracle's logits put them: %.2e" % differ)
+    assert differ < 5e-3 and abs(float(w_dev.mean() / w_ref.mean()) - 1) < 1e-2
+    conv_names = [n.name for n in net.nodes if n.op == "conv"]
+    masks = {k: (P.a[k][..., :net.layers[k].channels] > 0).double().cpu() for k in conv_names}
+    o = co.loss_and_grads(r["params"], r["grid"], r["labels"], masks=masks, cell_weights=P.weight.double().cpu(),
+                          activation="sigmoid", ghm_weights=w_dev)
+    ml, rg, tl = eng.losses(P)
+    assert abs(ml - float(o["model_loss"])) < 1e-4 * abs(float(o["model_loss"]))
+    gerr = {k: rel2(eng.grads[k], g)[0] for k, g in o["grads"].items()}
+    print("GHM grad rel-L2", {k: "%.1e" % v for k, v in gerr.items()})
+    for k, e in gerr.items():
+        # the logits bias sits in front of sigmoid + instance norm: its gradient is a small difference of
+        # large terms (the norm cancels a constant shift to first order), measured 1.7e-3; the rest ~1e-4
+        assert e < (1e-2 if k == "cls_logits/biases" else 1e-3), (k, e)
+    out = Trainer(eng, learning_rate=1e-4).step({"grid_table": r["grid"].unsqueeze(-1), "gt_classes": r["labels"]})
+    assert np.isfinite(out["total_loss"]) and out["global_norm"] > 0
