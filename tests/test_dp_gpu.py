@@ -48,11 +48,13 @@ def test_backward_hook_path_matches_plain_path():
     reg_plain = eng.losses(P)[1]
     # run-to-run noise of the plain path itself: the instance-norm moments are float atomics, the
     # last-bit differences grow layer by layer and a ReLU on its kink flips a whole local gradient
-    P = eng.forward(grid, labels=labels)
-    eng.loss_backward(P)
-    torch.cuda.synchronize()
     nrm = np.linalg.norm(plain.astype(np.float64))
-    noise = np.linalg.norm((eng.grads_flat.cpu().numpy() - plain).astype(np.float64))
+    noise = 0.0
+    for _ in range(3):          # the largest of three samples: one sample alone can come out small
+        P = eng.forward(grid, labels=labels)
+        eng.loss_backward(P)
+        torch.cuda.synchronize()
+        noise = max(noise, np.linalg.norm((eng.grads_flat.cpu().numpy() - plain).astype(np.float64)))
     print("run-to-run gradient noise (rel-L2): %.2e" % (noise / nrm))
 
     buckets = GradBuckets(eng.grads_flat, eng.n_conv_w, n_buckets=3)
