@@ -38,6 +38,7 @@ class SumRowsDesc(ctypes.Structure):
 
 
 MAX_BATCH = 32
+POOL_TILES = 32
 
 _c = ctypes
 _vp, _i, _i64, _f, _sz = _c.c_void_p, _c.c_int, _c.c_int64, _c.c_float, _c.c_size_t
@@ -51,15 +52,18 @@ SIGNATURES = {
                               _vp, _sz, _vp]),
     "cutie_embed_fwd": (_i, [_vp, _i64, _vp, _i, _i, _vp, _i, _i, _vp, _vp]),
     "cutie_embed_bwd": (_i, [_vp, _i64, _vp, _i, _i, _vp, _i, _i, _vp]),
-    "cutie_conv_fwd": (_i, [_c.POINTER(ConvSeg), _i, _i, _i, _i, _i, _vp, _i, _i, _vp, _i, _vp, _i, _vp]),
+    "cutie_conv_stats_tiles": (_i, [_i, _i]),
+    "cutie_conv_fwd": (_i, [_c.POINTER(ConvSeg), _i, _i, _i, _i, _i, _vp, _i, _i, _vp, _i, _vp, _i, _i, _vp]),
     "cutie_conv_wgrad_workspace_bytes": (_sz, [_i, _i, _i, _i, _i, _i, _i]),
     "cutie_conv_wgrad": (_i, [_vp, _i, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _i, _i, _vp, _sz, _vp]),
     "cutie_pack_weights": (_i, [_vp, _i, _i, _i, _vp, _i, _vp, _i, _i, _vp]),
     "cutie_pack_weights_batched": (_i, [_c.POINTER(PackDesc), _i, _i, _vp]),
-    "cutie_in_stats": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp]),
-    "cutie_in_apply": (_i, [_vp, _i, _i, _vp, _f, _vp, _i, _i, _i, _i, _i, _vp]),
-    "cutie_in_bwd_stats": (_i, [_vp, _i, _i, _vp, _i, _i, _vp, _f, _vp, _i, _i, _i, _vp]),
-    "cutie_in_bwd_apply": (_i, [_vp, _i, _i, _vp, _i, _i, _vp, _f, _vp, _i, _vp, _i, _i, _vp, _i, _i, _i, _vp]),
+    "cutie_in_tiles": (_i, [_i, _i, _i]),
+    "cutie_in_stats": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _i, _vp]),
+    "cutie_in_apply": (_i, [_vp, _i, _i, _vp, _i, _f, _vp, _i, _i, _i, _i, _i, _vp]),
+    "cutie_in_bwd_stats": (_i, [_vp, _i, _i, _vp, _i, _i, _vp, _i, _f, _vp, _i, _i, _i, _i, _vp]),
+    "cutie_in_bwd_apply": (_i, [_vp, _i, _i, _vp, _i, _i, _vp, _i, _f, _vp, _i, _i, _vp, _i, _i, _vp, _i, _i, _i, _i,
+                                _vp]),
     "cutie_sum_rows": (_i, [_vp, _i, _i, _vp, _i, _vp]),
     "cutie_sum_rows_batched": (_i, [_c.POINTER(SumRowsDesc), _i, _i, _i, _vp]),
     "cutie_spatial_mean_bcast": (_i, [_vp, _i, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp]),

@@ -24,7 +24,8 @@ struct ConvParams {
     int ld_out;
     const float* bias;
     int relu;
-    float* stats;
+    float* stats;        // [B][stats_tiles][n_out][2]: this launch stores slot (tile row * tiles_w + tile col)
+    int stats_tiles;
     int TH, TWB, tiles_h, tiles_w, n_tiles_n;
     int a_bytes;  // LDS bytes reserved for the A patch
 };

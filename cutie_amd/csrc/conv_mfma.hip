@@ -248,20 +248,22 @@ __global__ __launch_bounds__(CONV_NT, 2) void conv_kernel(ConvParams p) {
         ssum[n] = s1;
         ssq[n] = s2;
     }
+    float2* wsum = reinterpret_cast<float2*>(smem + 256 * 128 * sizeof(TO));   // [2 pixel halves][128 channels]
     if (p.stats) {
 #pragma unroll
         for (int n = 0; n < 4; ++n) {
             float s1 = ssum[n], s2 = ssq[n];
             s1 += __shfl_xor(s1, 16, 64); s1 += __shfl_xor(s1, 32, 64);
             s2 += __shfl_xor(s2, 16, 64); s2 += __shfl_xor(s2, 32, 64);
-            const int col = n0 + wn * 64 + n * 16 + li;
-            if (lg == 0 && col < n_out) {
-                atomicAdd(p.stats + ((long long)b * n_out + col) * 2 + 0, s1);
-                atomicAdd(p.stats + ((long long)b * n_out + col) * 2 + 1, s2);
-            }
+            if (lg == 0) wsum[wm * 128 + wn * 64 + n * 16 + li] = make_float2(s1, s2);
         }
     }
     __syncthreads();
+    if (p.stats && tid < 128 && n0 + tid < n_out) {     // the tile's slot: stored, never added to (no atomics)
+        const float2 u = wsum[tid], v = wsum[128 + tid];
+        *reinterpret_cast<float2*>(p.stats + (((long long)b * p.stats_tiles + (th * p.tiles_w + tw)) * n_out + n0 + tid) * 2) =
+            make_float2(u.x + v.x, u.y + v.y);
+    }
     constexpr int EPC = 16 / sizeof(TO);         // elements per 16-byte piece
     constexpr int PIECES = 128 / EPC;            // pieces per pixel row of the tile
     for (int idx = tid; idx < 256 * PIECES; idx += CONV_NT) {
@@ -713,9 +715,33 @@ int launch_conv(const ConvParams& p, size_t lds, hipStream_t stream) {
 
 }  // namespace
 
+namespace {
+// 256-pixel tilings of the two kernels: (rows, 16-pixel column blocks) per tile
+inline void generic_tiling(int W, int& th, int& twb) {
+    twb = 1;
+    while (twb < 8 && twb * 16 < W) twb *= 2;
+    th = 16 / twb;
+}
+inline void wide_tiling(int H, int W, int& th, int& tcb) {
+    th = 16;
+    tcb = 1;
+    while (th > 1 && th / 2 >= H && tcb * 16 < W) { th /= 2; tcb *= 2; }
+}
+}  // namespace
+
+extern "C" int cutie_conv_stats_tiles(int H, int W) {
+    if (H < 1 || W < 1) return 1;
+    int th, tb;
+    generic_tiling(W, th, tb);
+    const long long g = cutie::cdiv(H, th) * cutie::cdiv(W, tb * 16);
+    wide_tiling(H, W, th, tb);
+    const long long w = cutie::cdiv(H, th) * cutie::cdiv(W, tb * 16);
+    return (int)(g > w ? g : w);
+}
+
 extern "C" int cutie_conv_fwd(const cutie_conv_seg* segs, int n_segs, int B, int H, int W, int n_out, void* out,
-                              int ld_out, int out_dtype, const float* bias, int relu, float* stats, int dtype,
-                              cutie_stream_t stream_) {
+                              int ld_out, int out_dtype, const float* bias, int relu, float* stats, int stats_tiles,
+                              int dtype, cutie_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     CUTIE_CHECK_ARG(segs && n_segs >= 1 && n_segs <= CUTIE_MAX_SEGS, "conv_fwd: n_segs=%d (1..%d)", n_segs, CUTIE_MAX_SEGS);
     CUTIE_CHECK_ARG(B >= 0 && H >= 1 && W >= 1 && n_out >= 1 && ld_out >= n_out, "conv_fwd: bad sizes B=%d H=%d W=%d n_out=%d ld_out=%d",
@@ -731,10 +757,10 @@ extern "C" int cutie_conv_fwd(const cutie_conv_seg* segs, int n_segs, int B, int
 
     ConvParams p;
     p.nseg = n_segs;
-    int twb = 1;
-    while (twb < 8 && twb * 16 < W) twb *= 2;
+    int twb, th_g;
+    generic_tiling(W, th_g, twb);
     p.TWB = twb;
-    p.TH = 16 / twb;      // 16 pixel blocks = 256 pixels per tile
+    p.TH = th_g;          // 16 pixel blocks = 256 pixels per tile
     p.tiles_h = (int)cutie::cdiv(H, p.TH);
     p.tiles_w = (int)cutie::cdiv(W, twb * 16);
     p.n_tiles_n = (int)cutie::cdiv(n_out, 128);
@@ -764,10 +790,13 @@ extern "C" int cutie_conv_fwd(const cutie_conv_seg* segs, int n_segs, int B, int
     }
     p.a_bytes = a_bytes;
     p.B = B; p.H = H; p.W = W; p.n_out = n_out;
-    p.out = (char*)out; p.ld_out = ld_out; p.bias = bias; p.relu = relu; p.stats = stats;
+    p.out = (char*)out; p.ld_out = ld_out; p.bias = bias; p.relu = relu; p.stats = stats; p.stats_tiles = stats_tiles;
+    CUTIE_CHECK_ARG(!stats || stats_tiles >= cutie_conv_stats_tiles(H, W),
+                    "conv_fwd: stats_tiles=%d < cutie_conv_stats_tiles(%d, %d) = %d", stats_tiles, H, W, cutie_conv_stats_tiles(H, W));
+    CUTIE_CHECK_ARG(!stats || (reinterpret_cast<uintptr_t>(stats) & 7) == 0, "conv_fwd: stats must be 8-byte aligned");
     const size_t oes = out_dtype == CUTIE_F32 ? 4 : 2;
     size_t lds = (size_t)a_bytes + 2 * 128 * 128;
-    if (lds < 256 * 128 * oes) lds = 256 * 128 * oes;
+    if (lds < 256 * 128 * oes + 2 * 128 * 8) lds = 256 * 128 * oes + 2 * 128 * 8;    // staged tile + per-wave moments
     CUTIE_CHECK_ARG(lds <= 160 * 1024, "conv_fwd: tile needs %zu B of LDS (dilation %d too large for W=%d)", lds,
                     segs[0].dil, W);
     CUTIE_CHECK_ARG((long long)B * p.tiles_h * p.tiles_w * p.n_tiles_n < (1ll << 31), "conv_fwd: grid too large");
@@ -776,8 +805,8 @@ extern "C" int cutie_conv_fwd(const cutie_conv_seg* segs, int n_segs, int B, int
     const int bn = (wide_on && dtype != CUTIE_F32 && out_dtype == dtype) ? cutie::conv_wide_tile(p) : 0;
     if (bn) {
         ConvParams q = p;
-        int th = 16, tcb = 1;
-        while (th > 1 && th / 2 >= H && tcb * 16 < W) { th /= 2; tcb *= 2; }
+        int th, tcb;
+        wide_tiling(H, W, th, tcb);
         q.TH = th; q.TWB = tcb;
         q.tiles_h = (int)cutie::cdiv(H, th);
         q.tiles_w = (int)cutie::cdiv(W, tcb * 16);

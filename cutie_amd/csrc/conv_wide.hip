@@ -32,13 +32,14 @@ template <int BN> struct Shape {
     static constexpr int NB = BN / 64;          // 1-KB pieces of the B tile each wave stages per step
     static constexpr int NP = 4 + NB;           // pieces per wave and step (A: always 4)
     static constexpr int BBUF = BN * 128;
-    static constexpr int LDS = CW_B0 + 2 * BBUF;
+    static constexpr int WSUM = 256 * BN * 2;   // per-wave instance-norm partials sit behind the staged output tile
+    static constexpr int LDS = (CW_B0 + 2 * BBUF > WSUM + WM * BN * 8) ? CW_B0 + 2 * BBUF : WSUM + WM * BN * 8;
 };
 
 // bias, ReLU, instance-norm moments, LDS-staged coalesced store of a 256-pixel x BN-channel tile
 template <int DT, int BN>
 __device__ __forceinline__ void conv_wide_epilogue(const ConvParams& p, float4_t (&acc)[Shape<BN>::MB][4], char* smem, int b,
-                                                   int h0, int w0, int n0) {
+                                                   int tile, int h0, int w0, int n0) {
     typedef Shape<BN> S;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -49,6 +50,7 @@ __device__ __forceinline__ void conv_wide_epilogue(const ConvParams& p, float4_t
     __syncthreads();
     typedef typename elem<DT>::type TO;
     TO* Cs = reinterpret_cast<TO*>(smem);  // [256 pixels][BN channels]
+    float2* wsum = reinterpret_cast<float2*>(smem + S::WSUM);   // [WM][BN]
 #pragma unroll
     for (int n = 0; n < 4; ++n) {
         const int cl = wn * 64 + n * 16 + li;
@@ -73,13 +75,22 @@ __device__ __forceinline__ void conv_wide_epilogue(const ConvParams& p, float4_t
         if (p.stats) {
             s1 += __shfl_xor(s1, 16, 64); s1 += __shfl_xor(s1, 32, 64);
             s2 += __shfl_xor(s2, 16, 64); s2 += __shfl_xor(s2, 32, 64);
-            if (lg == 0 && col < n_out) {
-                atomicAdd(p.stats + ((long long)b * n_out + col) * 2 + 0, s1);
-                atomicAdd(p.stats + ((long long)b * n_out + col) * 2 + 1, s2);
-            }
+            if (lg == 0) wsum[wm * BN + cl] = make_float2(s1, s2);
         }
     }
     __syncthreads();
+    if (p.stats && tid < BN && n0 + tid < n_out) {
+        // the tile's moments: the waves' partials added in wave order, STORED into this tile's slot -
+        // no float atomics, so reruns (and the ReLU patterns downstream) are bit-identical
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int w = 0; w < S::WM; ++w) {
+            const float2 v = wsum[w * BN + tid];
+            s1 += v.x;
+            s2 += v.y;
+        }
+        *reinterpret_cast<float2*>(p.stats + (((long long)b * p.stats_tiles + tile) * n_out + n0 + tid) * 2) = make_float2(s1, s2);
+    }
     constexpr int PPR = BN / 8;                                   // 16-byte pieces per pixel row
     for (int idx = tid; idx < 256 * PPR; idx += CW_NT) {
         const int ml = idx / PPR, pc = idx % PPR;
@@ -275,7 +286,7 @@ __global__ __launch_bounds__(CW_NT) void conv_wide_kernel(ConvParams p) {
         buf ^= 1;
     }
 
-    conv_wide_epilogue<DT, BN>(p, acc, smem, b, h0, w0, n0);
+    conv_wide_epilogue<DT, BN>(p, acc, smem, b, th * p.tiles_w + tw, h0, w0, n0);
 }
 
 

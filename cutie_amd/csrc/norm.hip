@@ -88,18 +88,31 @@ __device__ __forceinline__ Map make_map(int HW, int CV) {
     return m;
 }
 
-__device__ __forceinline__ void mean_inv(const float* stats, int b, int C, int c, float inv_n, float eps,
+// Partial-sum layout shared by stats, red and dbias_part: [B][T][C](x2) - every producer workgroup (a
+// conv tile, a slice of H*W) owns slot t and STORES its sum there; consumers add the T slots in slot
+// order.  No float atomics anywhere on this path: reruns are bit-identical.
+__device__ __forceinline__ void sum_tiles(const float* p, int b, int T, int C, int c, float& s0, float& s1) {
+    s0 = 0.f;
+    s1 = 0.f;
+    for (int t = 0; t < T; ++t) {
+        const float2 v = *reinterpret_cast<const float2*>(p + (((int64_t)b * T + t) * C + c) * 2);
+        s0 += v.x;
+        s1 += v.y;
+    }
+}
+
+__device__ __forceinline__ void mean_inv(const float* stats, int b, int T, int C, int c, float inv_n, float eps,
                                          float& mean, float& inv) {
-    const float s = stats[((int64_t)b * C + c) * 2 + 0];
-    const float ss = stats[((int64_t)b * C + c) * 2 + 1];
+    float s, ss;
+    sum_tiles(stats, b, T, C, c, s, ss);
     mean = s * inv_n;
     const float var = fmaxf(ss * inv_n - mean * mean, 0.f);
     inv = rsqrtf(var + eps);
 }
 
-// red[NRED][256][VEC] in LDS -> sum over the side-by-side rows -> atomicAdd(dst(c, k))
+// red[NRED][256][VEC] in LDS -> sum over the side-by-side rows (fixed order) -> *dst(c, k) = sum
 template <int VEC, int NRED, typename F>
-__device__ __forceinline__ void block_reduce_atomic(float (*red)[256][VEC], const Map& m, int CV, F&& dst) {
+__device__ __forceinline__ void block_reduce_store(float (*red)[256][VEC], const Map& m, int CV, F&& dst) {
     __syncthreads();
     const int C = CV * VEC;
     for (int idx = threadIdx.x; idx < NRED * C; idx += 256) {      // all lanes share the tail
@@ -107,7 +120,7 @@ __device__ __forceinline__ void block_reduce_atomic(float (*red)[256][VEC], cons
         const int cl = c / VEC, e = c - cl * VEC;
         float s = 0.f;
         for (int r = 0; r < m.rows_par; ++r) s += red[k][r * CV + cl][e];
-        atomicAdd(dst(c, k), s);
+        *dst(c, k) = s;
     }
 }
 
@@ -127,13 +140,13 @@ __global__ __launch_bounds__(256) void in_stats_kernel(const TA* __restrict__ a,
     }
 #pragma unroll
     for (int e = 0; e < VEC; ++e) { red[0][threadIdx.x][e] = s[e]; red[1][threadIdx.x][e] = ss[e]; }
-    const int b = m.b;
-    block_reduce_atomic<VEC, 2>(red, m, CV, [&](int c, int k) { return stats + ((int64_t)b * C + c) * 2 + k; });
+    const int64_t slot = (int64_t)m.b * gridDim.x + blockIdx.x;
+    block_reduce_store<VEC, 2>(red, m, CV, [&](int c, int k) { return stats + (slot * C + c) * 2 + k; });
 }
 
 template <int VEC, typename TA, typename TY>
 __global__ __launch_bounds__(256) void in_apply_kernel(const TA* __restrict__ a, int ld_a,
-                                                       const float* __restrict__ stats, float eps,
+                                                       const float* __restrict__ stats, int st, float eps,
                                                        TY* __restrict__ y, int ld_y, int HW, int C) {
     const int CV = C / VEC;
     const Map m = make_map(HW, CV);
@@ -141,7 +154,7 @@ __global__ __launch_bounds__(256) void in_apply_kernel(const TA* __restrict__ a,
     const float inv_n = 1.f / (float)HW;
     float mean[VEC], inv[VEC];
 #pragma unroll
-    for (int e = 0; e < VEC; ++e) mean_inv(stats, m.b, C, m.cl * VEC + e, inv_n, eps, mean[e], inv[e]);
+    for (int e = 0; e < VEC; ++e) mean_inv(stats, m.b, st, C, m.cl * VEC + e, inv_n, eps, mean[e], inv[e]);
     for (int hw = m.hw0 + m.sub; hw < m.hw1; hw += m.rows_par) {
         const int64_t row = (int64_t)m.b * HW + hw;
         vecf<VEC> x = loadv<VEC>(a + row * ld_a + m.cl * VEC);
@@ -154,7 +167,7 @@ __global__ __launch_bounds__(256) void in_apply_kernel(const TA* __restrict__ a,
 template <int VEC, typename TD, typename TA>
 __global__ __launch_bounds__(256) void in_bwd_stats_kernel(const TD* __restrict__ dy, int ld_dy,
                                                            const TA* __restrict__ a, int ld_a,
-                                                           const float* __restrict__ stats, float eps,
+                                                           const float* __restrict__ stats, int st, float eps,
                                                            float* __restrict__ redout, int HW, int C) {
     __shared__ float red[2][256][VEC];
     const int CV = C / VEC;
@@ -164,7 +177,7 @@ __global__ __launch_bounds__(256) void in_bwd_stats_kernel(const TD* __restrict_
         const float inv_n = 1.f / (float)HW;
         float mean[VEC], inv[VEC];
 #pragma unroll
-        for (int e = 0; e < VEC; ++e) mean_inv(stats, m.b, C, m.cl * VEC + e, inv_n, eps, mean[e], inv[e]);
+        for (int e = 0; e < VEC; ++e) mean_inv(stats, m.b, st, C, m.cl * VEC + e, inv_n, eps, mean[e], inv[e]);
 #pragma unroll 4
         for (int hw = m.hw0 + m.sub; hw < m.hw1; hw += m.rows_par) {
             const int64_t row = (int64_t)m.b * HW + hw;
@@ -179,15 +192,15 @@ __global__ __launch_bounds__(256) void in_bwd_stats_kernel(const TD* __restrict_
     }
 #pragma unroll
     for (int e = 0; e < VEC; ++e) { red[0][threadIdx.x][e] = s1[e]; red[1][threadIdx.x][e] = s2[e]; }
-    const int b = m.b;
-    block_reduce_atomic<VEC, 2>(red, m, CV, [&](int c, int k) { return redout + ((int64_t)b * C + c) * 2 + k; });
+    const int64_t slot = (int64_t)m.b * gridDim.x + blockIdx.x;
+    block_reduce_store<VEC, 2>(red, m, CV, [&](int c, int k) { return redout + (slot * C + c) * 2 + k; });
 }
 
 template <int VEC, typename TD, typename TA, typename TZ>
 __global__ __launch_bounds__(256) void in_bwd_apply_kernel(const TD* __restrict__ dy, int ld_dy,
                                                            const TA* __restrict__ a, int ld_a,
-                                                           const float* __restrict__ stats, float eps,
-                                                           const float* __restrict__ redin, int relu,
+                                                           const float* __restrict__ stats, int st, float eps,
+                                                           const float* __restrict__ redin, int rt, int relu,
                                                            TZ* __restrict__ dz, int ld_dz,
                                                            float* __restrict__ dbias, int HW, int C) {
     __shared__ float red[1][256][VEC];
@@ -200,9 +213,10 @@ __global__ __launch_bounds__(256) void in_bwd_apply_kernel(const TD* __restrict_
 #pragma unroll
         for (int e = 0; e < VEC; ++e) {
             const int c = m.cl * VEC + e;
-            mean_inv(stats, m.b, C, c, inv_n, eps, mean[e], inv[e]);
-            m1[e] = redin[((int64_t)m.b * C + c) * 2 + 0] * inv_n;
-            m2[e] = redin[((int64_t)m.b * C + c) * 2 + 1] * inv_n;
+            mean_inv(stats, m.b, st, C, c, inv_n, eps, mean[e], inv[e]);
+            sum_tiles(redin, m.b, rt, C, c, m1[e], m2[e]);
+            m1[e] *= inv_n;
+            m2[e] *= inv_n;
         }
         for (int hw = m.hw0 + m.sub; hw < m.hw1; hw += m.rows_par) {
             const int64_t row = (int64_t)m.b * HW + hw;
@@ -224,22 +238,14 @@ __global__ __launch_bounds__(256) void in_bwd_apply_kernel(const TD* __restrict_
             storev<VEC>(dz + row * ld_dz + m.cl * VEC, o);
         }
     }
-    if (dbias) {   // per-(sample, channel) partials: B x fewer adders per address than dbias[c]
+    if (dbias) {   // one row of partials per (sample, H*W slice): [B * gridDim.x][C], folded by sum_rows
 #pragma unroll
         for (int e = 0; e < VEC; ++e) red[0][threadIdx.x][e] = sb[e];
-        const int b = m.b;
-        block_reduce_atomic<VEC, 1>(red, m, CV, [&](int c, int) { return dbias + (int64_t)b * C + c; });
+        const int64_t slot = (int64_t)m.b * gridDim.x + blockIdx.x;
+        block_reduce_store<VEC, 1>(red, m, CV, [&](int c, int) { return dbias + slot * C + c; });
     }
 }
 
-__global__ __launch_bounds__(256) void sum_rows_kernel(const float* __restrict__ part, int B, int C,
-                                                       float* __restrict__ out, int accumulate) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    float s = accumulate ? out[c] : 0.f;
-    for (int b = 0; b < B; ++b) s += part[(int64_t)b * C + c];
-    out[c] = s;
-}
 
 // one workgroup per (b, chunk of CV_BLK channel lanes): mean over HW, then broadcast
 template <int VEC, typename TX, typename TO>
@@ -282,8 +288,8 @@ __global__ __launch_bounds__(256) void mean_bcast_kernel(const TX* __restrict__ 
 
 // second half of the wide-grid global pool: out[b, hw, c] = sums[b][c][0] / HW
 template <int VEC, typename TO>
-__global__ __launch_bounds__(256) void bcast_mean_kernel(const float* __restrict__ sums, TO* __restrict__ out, int ld_out,
-                                                         int HW, int C, int rows_per_wg) {
+__global__ __launch_bounds__(256) void bcast_mean_kernel(const float* __restrict__ sums, int st, TO* __restrict__ out,
+                                                         int ld_out, int HW, int C, int rows_per_wg) {
     const int CV = C / VEC;
     const int b = blockIdx.y;
     const int rows_par = 256 / CV;
@@ -292,7 +298,11 @@ __global__ __launch_bounds__(256) void bcast_mean_kernel(const float* __restrict
     vecf<VEC> mv;
     const float inv = 1.f / (float)HW;
 #pragma unroll
-    for (int e = 0; e < VEC; ++e) mv.v[e] = sums[((int64_t)b * C + cl * VEC + e) * 2] * inv;
+    for (int e = 0; e < VEC; ++e) {
+        float s0, s1;
+        sum_tiles(sums, b, st, C, cl * VEC + e, s0, s1);
+        mv.v[e] = s0 * inv;
+    }
     const int r0 = blockIdx.x * rows_per_wg;
     const int r1 = min(HW, r0 + rows_per_wg);
     for (int hw = r0 + sub; hw < r1; hw += rows_par) storev<VEC>(out + ((int64_t)b * HW + hw) * ld_out + cl * VEC, mv);
@@ -321,6 +331,12 @@ inline dim3 reduce_grid(int B, int HW, int C, int vec) {
     return dim3(s, B);
 }
 
+inline int hint_tiles(int B, int HW, int C) {
+    const int vec = (C % 8 == 0 && C >= 64) ? 8 : (C % 4 == 0 ? 4 : 1);
+    if (C / vec > 256) return 1;
+    return (int)reduce_grid(B, HW, C, vec).x;
+}
+
 }  // namespace
 
 #define NORM_DISPATCH_VEC(vec, ...)                                   \
@@ -328,14 +344,20 @@ inline dim3 reduce_grid(int B, int HW, int C, int vec) {
     else if ((vec) == 4) { constexpr int VEC = 4; __VA_ARGS__; }      \
     else { constexpr int VEC = 1; __VA_ARGS__; }
 
-extern "C" int cutie_in_stats(const void* a, int ld_a, int a_dtype, int B, int HW, int C, float* stats,
+extern "C" int cutie_in_tiles(int B, int HW, int C) {
+    if (B < 1 || HW < 1 || C < 1) return 1;
+    return hint_tiles(B, HW, C);
+}
+
+extern "C" int cutie_in_stats(const void* a, int ld_a, int a_dtype, int B, int HW, int C, float* stats, int stats_tiles,
                               cutie_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     const int vec = pick_vec(C, {ld_a}, {a});
     if (int e = check_common("in_stats", B, HW, C, vec)) return e;
     if (B == 0) return CUTIE_OK;
     CUTIE_CHECK_ARG(a && stats && ld_a >= C, "in_stats: null pointer or ld < C");
-    const dim3 g = reduce_grid(B, HW, C, vec);
+    CUTIE_CHECK_ARG(stats_tiles >= 1 && stats_tiles <= 65535, "in_stats: stats_tiles=%d", stats_tiles);
+    const dim3 g(stats_tiles, B);
     CUTIE_DISPATCH_DTYPE(a_dtype, ADT, NORM_DISPATCH_VEC(vec,
         hipLaunchKernelGGL((in_stats_kernel<VEC, typename elem<ADT>::type>), g, dim3(256), 0, stream,
                            (const typename elem<ADT>::type*)a, ld_a, HW, C, stats)));
@@ -343,42 +365,45 @@ extern "C" int cutie_in_stats(const void* a, int ld_a, int a_dtype, int B, int H
     return CUTIE_OK;
 }
 
-extern "C" int cutie_in_apply(const void* a, int ld_a, int a_dtype, const float* stats, float eps, void* y,
-                              int ld_y, int y_dtype, int B, int HW, int C, cutie_stream_t stream_) {
+extern "C" int cutie_in_apply(const void* a, int ld_a, int a_dtype, const float* stats, int stats_tiles, float eps,
+                              void* y, int ld_y, int y_dtype, int B, int HW, int C, cutie_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     const int vec = pick_vec(C, {ld_a, ld_y}, {a, y});
     if (int e = check_common("in_apply", B, HW, C, vec)) return e;
     if (B == 0) return CUTIE_OK;
     CUTIE_CHECK_ARG(a && stats && y && ld_a >= C && ld_y >= C, "in_apply: null pointer or ld < C");
+    CUTIE_CHECK_ARG(stats_tiles >= 1, "in_apply: stats_tiles=%d", stats_tiles);
     const dim3 g = reduce_grid(B, HW, C, vec);
     CUTIE_DISPATCH_DTYPE(a_dtype, ADT, CUTIE_DISPATCH_DTYPE(y_dtype, YDT, NORM_DISPATCH_VEC(vec,
         hipLaunchKernelGGL((in_apply_kernel<VEC, typename elem<ADT>::type, typename elem<YDT>::type>), g, dim3(256),
-                           0, stream, (const typename elem<ADT>::type*)a, ld_a, stats, eps,
+                           0, stream, (const typename elem<ADT>::type*)a, ld_a, stats, stats_tiles, eps,
                            (typename elem<YDT>::type*)y, ld_y, HW, C))));
     CUTIE_CHECK_LAUNCH();
     return CUTIE_OK;
 }
 
 extern "C" int cutie_in_bwd_stats(const void* dy, int ld_dy, int dy_dtype, const void* a, int ld_a, int a_dtype,
-                                  const float* stats, float eps, float* red, int B, int HW, int C,
-                                  cutie_stream_t stream_) {
+                                  const float* stats, int stats_tiles, float eps, float* red, int red_tiles, int B,
+                                  int HW, int C, cutie_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     const int vec = pick_vec(C, {ld_dy, ld_a}, {dy, a});
     if (int e = check_common("in_bwd_stats", B, HW, C, vec)) return e;
     if (B == 0) return CUTIE_OK;
     CUTIE_CHECK_ARG(dy && a && stats && red && ld_dy >= C && ld_a >= C, "in_bwd_stats: null pointer or ld < C");
-    const dim3 g = reduce_grid(B, HW, C, vec);
+    CUTIE_CHECK_ARG(stats_tiles >= 1 && red_tiles >= 1 && red_tiles <= 65535, "in_bwd_stats: tiles %d / %d", stats_tiles, red_tiles);
+    const dim3 g(red_tiles, B);
     CUTIE_DISPATCH_DTYPE(dy_dtype, DDT, CUTIE_DISPATCH_DTYPE(a_dtype, ADT, NORM_DISPATCH_VEC(vec,
         hipLaunchKernelGGL((in_bwd_stats_kernel<VEC, typename elem<DDT>::type, typename elem<ADT>::type>), g,
                            dim3(256), 0, stream, (const typename elem<DDT>::type*)dy, ld_dy,
-                           (const typename elem<ADT>::type*)a, ld_a, stats, eps, red, HW, C))));
+                           (const typename elem<ADT>::type*)a, ld_a, stats, stats_tiles, eps, red, HW, C))));
     CUTIE_CHECK_LAUNCH();
     return CUTIE_OK;
 }
 
 extern "C" int cutie_in_bwd_apply(const void* dy, int ld_dy, int dy_dtype, const void* a, int ld_a, int a_dtype,
-                                  const float* stats, float eps, const float* red, int relu, void* dz, int ld_dz,
-                                  int dz_dtype, float* dbias, int B, int HW, int C, cutie_stream_t stream_) {
+                                  const float* stats, int stats_tiles, float eps, const float* red, int red_tiles,
+                                  int relu, void* dz, int ld_dz, int dz_dtype, float* dbias, int dbias_tiles, int B,
+                                  int HW, int C, cutie_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     const int vec = pick_vec(C, {ld_dy, ld_a, ld_dz}, {dy, a, dz});
     if (int e = check_common("in_bwd_apply", B, HW, C, vec)) return e;
@@ -386,20 +411,15 @@ extern "C" int cutie_in_bwd_apply(const void* dy, int ld_dy, int dy_dtype, const
     CUTIE_CHECK_ARG(dy && a && stats && red && dz && ld_dy >= C && ld_a >= C && ld_dz >= C,
                     "in_bwd_apply: null pointer or ld < C");
     CUTIE_CHECK_ARG(a_dtype == dz_dtype, "in_bwd_apply: dz dtype must equal a dtype");
-    const dim3 g = reduce_grid(B, HW, C, vec);
+    CUTIE_CHECK_ARG(stats_tiles >= 1 && red_tiles >= 1 && (!dbias || (dbias_tiles >= 1 && dbias_tiles <= 65535)),
+                    "in_bwd_apply: tiles %d / %d / %d", stats_tiles, red_tiles, dbias_tiles);
+    const dim3 g = dbias ? dim3(dbias_tiles, B) : reduce_grid(B, HW, C, vec);
     CUTIE_DISPATCH_DTYPE(dy_dtype, DDT, CUTIE_DISPATCH_DTYPE(a_dtype, ADT, NORM_DISPATCH_VEC(vec,
         hipLaunchKernelGGL((in_bwd_apply_kernel<VEC, typename elem<DDT>::type, typename elem<ADT>::type,
                                                 typename elem<ADT>::type>), g, dim3(256), 0, stream,
                            (const typename elem<DDT>::type*)dy, ld_dy, (const typename elem<ADT>::type*)a, ld_a,
-                           stats, eps, red, relu, (typename elem<ADT>::type*)dz, ld_dz, dbias, HW, C))));
-    CUTIE_CHECK_LAUNCH();
-    return CUTIE_OK;
-}
-
-extern "C" int cutie_sum_rows(const float* part, int B, int C, float* out, int accumulate, cutie_stream_t stream_) {
-    hipStream_t stream = (hipStream_t)stream_;
-    CUTIE_CHECK_ARG(B >= 0 && C >= 1 && part && out, "sum_rows: bad arguments");
-    hipLaunchKernelGGL(sum_rows_kernel, dim3((C + 255) / 256), dim3(256), 0, stream, part, B, C, out, accumulate);
+                           stats, stats_tiles, eps, red, red_tiles, relu, (typename elem<ADT>::type*)dz, ld_dz, dbias,
+                           HW, C))));
     CUTIE_CHECK_LAUNCH();
     return CUTIE_OK;
 }
@@ -408,13 +428,27 @@ namespace {
 struct SumRowsBatch {
     cutie_sum_rows_desc d[CUTIE_MAX_BATCH];
 };
+// out[c] (+)= sum over rows of part[row][c]: 16 channels x 16 row lanes per workgroup, each lane adds its
+// rows (row, row + 16, ...) in order, the 16 lane sums are added in lane order - a fixed order throughout
 __global__ __launch_bounds__(256) void sum_rows_batched_kernel(SumRowsBatch sb, int B, int accumulate) {
+    __shared__ float red[16][17];
     const cutie_sum_rows_desc d = sb.d[blockIdx.y];
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= d.C) return;
-    float s = accumulate ? d.out[c] : 0.f;
-    for (int b = 0; b < B; ++b) s += d.part[(int64_t)b * d.C + c];
-    d.out[c] = s;
+    const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
+    const int c = blockIdx.x * 16 + cl;
+    if (blockIdx.x * 16 >= d.C) return;
+    float s = 0.f;
+    if (c < d.C) {
+#pragma unroll 4
+        for (int b = rl; b < B; b += 16) s += d.part[(int64_t)b * d.C + c];
+    }
+    red[rl][cl] = s;
+    __syncthreads();
+    if (rl == 0 && c < d.C) {
+        float t = accumulate ? d.out[c] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) t += red[r][cl];
+        d.out[c] = t;
+    }
 }
 }  // namespace
 
@@ -430,9 +464,15 @@ extern "C" int cutie_sum_rows_batched(const cutie_sum_rows_desc* descs, int n, i
         sb.d[i] = descs[i];
         if (descs[i].C > cmax) cmax = descs[i].C;
     }
-    hipLaunchKernelGGL(sum_rows_batched_kernel, dim3((cmax + 255) / 256, n), dim3(256), 0, stream, sb, B, accumulate);
+    hipLaunchKernelGGL(sum_rows_batched_kernel, dim3((cmax + 15) / 16, n), dim3(256), 0, stream, sb, B, accumulate);
     CUTIE_CHECK_LAUNCH();
     return CUTIE_OK;
+}
+
+extern "C" int cutie_sum_rows(const float* part, int B, int C, float* out, int accumulate, cutie_stream_t stream_) {
+    CUTIE_CHECK_ARG(B >= 0 && C >= 1 && part && out, "sum_rows: bad arguments");
+    const cutie_sum_rows_desc d = {part, out, C};
+    return cutie_sum_rows_batched(&d, 1, B, accumulate, stream_);      // one order of summation for both entry points
 }
 
 extern "C" int cutie_spatial_mean_bcast(const void* x, int ld_x, int x_dtype, void* out, int ld_out, int out_dtype,
@@ -444,17 +484,17 @@ extern "C" int cutie_spatial_mean_bcast(const void* x, int ld_x, int x_dtype, vo
     CUTIE_CHECK_ARG(x && out && ld_x >= C && ld_out >= C, "spatial_mean_bcast: null pointer or ld < C");
     const int CV = C / vec;
     if (scratch && CV <= 256) {
-        // wide grid: the per-(b, c) sums by the instance-norm statistics pass (thousands of
-        // workgroups, one f32 atomic per workgroup and channel), then a pure store pass
-        CUTIE_CHECK_HIP(hipMemsetAsync(scratch, 0, (size_t)B * C * 2 * sizeof(float), stream));
-        const int rc = cutie_in_stats(x, ld_x, x_dtype, B, HW, C, scratch, stream_);
+        // wide grid: per-(b, c) partial sums by the instance-norm statistics pass (CUTIE_POOL_TILES
+        // slices of H*W per sample, one slot each), then a store pass that adds the slots in order
+        const int st = CUTIE_POOL_TILES;
+        const int rc = cutie_in_stats(x, ld_x, x_dtype, B, HW, C, scratch, st, stream_);
         if (rc != CUTIE_OK) return rc;
         const int rows_par = 256 / CV;
         int rows_per_wg = rows_par * 8;
         const dim3 g((HW + rows_per_wg - 1) / rows_per_wg, B);
         CUTIE_DISPATCH_DTYPE(out_dtype, ODT, NORM_DISPATCH_VEC(vec,
             hipLaunchKernelGGL((bcast_mean_kernel<VEC, typename elem<ODT>::type>), g, dim3(256), 0, stream,
-                               (const float*)scratch, (typename elem<ODT>::type*)out, ld_out, HW, C, rows_per_wg)));
+                               (const float*)scratch, st, (typename elem<ODT>::type*)out, ld_out, HW, C, rows_per_wg)));
         CUTIE_CHECK_LAUNCH();
         return CUTIE_OK;
     }

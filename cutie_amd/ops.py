@@ -128,7 +128,8 @@ ACTIVATION_CODE = {None: 0, False: 0, "none": 0, True: 1, "relu": 1, "sigmoid": 
 
 def conv_fwd(segs, out, n_out, bias=None, relu=False, stats=None):
     """segs: list of dict(x=[B,H,W,>=cin] view, w=packed [taps, n_rows, cin], cin, kh, kw, dil, flip,
-    n_off=row offset into w).  out: [B,H,W,>=n_out] view."""
+    n_off=row offset into w).  out: [B,H,W,>=n_out] view.  stats: zeroed f32 [B, T, n_out, 2] with
+    T >= conv_stats_tiles(H, W): per-tile partial moments (sum over T for the totals)."""
     B, H, W = out.shape[0], out.shape[1], out.shape[2]
     arr = (ConvSeg * len(segs))()
     dt = None
@@ -155,7 +156,7 @@ def conv_fwd(segs, out, n_out, bias=None, relu=False, stats=None):
         arr[i].kh, arr[i].kw, arr[i].dil = s["kh"], s["kw"], s["dil"]
         arr[i].flip = 1 if s.get("flip") else 0
     call("cutie_conv_fwd", arr, len(segs), B, H, W, n_out, ptr(out), ld_of(out), dt_of(out), ptr(bias),
-         ACTIVATION_CODE[relu], ptr(stats), dt, stream())
+         ACTIVATION_CODE[relu], ptr(stats), _tiles(stats, B, n_out, True), dt, stream())
     return out
 
 
@@ -176,31 +177,52 @@ def _bhwc(t):
     return t.shape[0], t.shape[1] * t.shape[2], t.shape[3]
 
 
+def _tiles(t, B, C, last2):
+    """slot count of a partial-sum tensor: [B, T, C, 2] / [B, C, 2] (T = 1) when last2, else [B*T, C]"""
+    if t is None:
+        return 0
+    if not t.is_contiguous() or t.dtype != torch.float32:
+        raise capi.CutieError("partial sums must be contiguous f32")
+    per = C * (2 if last2 else 1)
+    if t.numel() % (B * per):
+        raise capi.CutieError("partial-sum tensor %s does not hold whole [B=%d][T][C=%d] slots" % (tuple(t.shape), B, C))
+    return t.numel() // (B * per)
+
+
+def conv_stats_tiles(H, W):
+    return capi.lib().cutie_conv_stats_tiles(int(H), int(W))
+
+
+def in_tiles(B, HW, C):
+    return capi.lib().cutie_in_tiles(int(B), int(HW), int(C))
+
+
 def in_stats(a, stats):
     B, HW, C = _bhwc(a)
-    call("cutie_in_stats", ptr(a), ld_of(a), dt_of(a), B, HW, C, ptr(stats), stream())
+    call("cutie_in_stats", ptr(a), ld_of(a), dt_of(a), B, HW, C, ptr(stats), _tiles(stats, B, C, True), stream())
     return stats
 
 
 def in_apply(a, stats, y, eps=IN_EPS):
     B, HW, C = _bhwc(a)
-    call("cutie_in_apply", ptr(a), ld_of(a), dt_of(a), ptr(stats), eps, ptr(y), ld_of(y), dt_of(y), B, HW, C,
-         stream())
+    call("cutie_in_apply", ptr(a), ld_of(a), dt_of(a), ptr(stats), _tiles(stats, B, C, True), eps, ptr(y), ld_of(y),
+         dt_of(y), B, HW, C, stream())
     return y
 
 
 def in_bwd_stats(dy, a, stats, red, eps=IN_EPS):
     B, HW, C = _bhwc(a)
-    call("cutie_in_bwd_stats", ptr(dy), ld_of(dy), dt_of(dy), ptr(a), ld_of(a), dt_of(a), ptr(stats), eps,
-         ptr(red), B, HW, C, stream())
+    call("cutie_in_bwd_stats", ptr(dy), ld_of(dy), dt_of(dy), ptr(a), ld_of(a), dt_of(a), ptr(stats),
+         _tiles(stats, B, C, True), eps, ptr(red), _tiles(red, B, C, True), B, HW, C, stream())
     return red
 
 
 def in_bwd_apply(dy, a, stats, red, dz, dbias_part=None, relu=True, eps=IN_EPS):
-    """dbias_part: f32 [B, C] zeroed partial sums (fold with sum_rows)."""
+    """dbias_part: f32 [B * T, C] partial sums, one row per (sample, slice of H*W) (fold with sum_rows)."""
     B, HW, C = _bhwc(a)
-    call("cutie_in_bwd_apply", ptr(dy), ld_of(dy), dt_of(dy), ptr(a), ld_of(a), dt_of(a), ptr(stats), eps,
-         ptr(red), ACTIVATION_CODE[relu], ptr(dz), ld_of(dz), dt_of(dz), ptr(dbias_part), B, HW, C, stream())
+    call("cutie_in_bwd_apply", ptr(dy), ld_of(dy), dt_of(dy), ptr(a), ld_of(a), dt_of(a), ptr(stats),
+         _tiles(stats, B, C, True), eps, ptr(red), _tiles(red, B, C, True), ACTIVATION_CODE[relu], ptr(dz), ld_of(dz),
+         dt_of(dz), ptr(dbias_part), _tiles(dbias_part, B, C, False), B, HW, C, stream())
     return dz
 
 
@@ -213,8 +235,8 @@ def sum_rows(part, out, accumulate=False):
 def spatial_mean_bcast(x, out, scratch=None):
     """scratch: optional f32 tensor of >= B*C*2 elements (clobbered) - selects the wide-grid path"""
     B, HW, C = _bhwc(x)
-    if scratch is not None and (scratch.dtype != torch.float32 or scratch.numel() < B * C * 2):
-        raise capi.CutieError("spatial_mean_bcast: scratch needs %d f32 elements" % (B * C * 2))
+    if scratch is not None and (scratch.dtype != torch.float32 or scratch.numel() < B * capi.POOL_TILES * C * 2):
+        raise capi.CutieError("spatial_mean_bcast: scratch needs %d f32 elements" % (B * capi.POOL_TILES * C * 2))
     call("cutie_spatial_mean_bcast", ptr(x), ld_of(x), dt_of(x), ptr(out), ld_of(out), dt_of(out), B, HW, C,
          ptr(scratch), stream())
     return out

@@ -180,21 +180,21 @@ class Engine(object):
         # ---- per conv layer state
         convs = [n for n in nodes if n.op == "conv"]
         P.convs = convs
-        n_stats = sum(B * n.channels * 2 for n in convs)
+        # instance-norm moments as per-tile partial sums [B][T][C][2] (slot stores, no float atomics)
+        tiles = {n.name: ops.conv_stats_tiles(*spatial(n)) for n in convs}
+        n_stats = sum(B * tiles[n.name] * n.channels * 2 for n in convs)
         P.stats_all = torch.zeros(n_stats, dtype=torch.float32, device=dev)
-        P.red_all = torch.zeros(n_stats + n_stats // 2, dtype=torch.float32, device=dev)
         P.a, P.stats, P.red, P.dz, P.dy, P.dbpart = {}, {}, {}, {}, {}, {}
         so = 0
         for n in convs:
             hs, ws = spatial(n)
             P.a[n.name] = torch.zeros((B, hs, ws, _pad(n.channels)), dtype=tdt, device=dev)
-            cnt = B * n.channels * 2
-            P.stats[n.name] = P.stats_all[so:so + cnt].view(B, n.channels, 2)
-            P.red[n.name] = P.red_all[so:so + cnt].view(B, n.channels, 2)
-            P.dbpart[n.name] = P.red_all[n_stats + so // 2:n_stats + (so + cnt) // 2].view(B, n.channels)
+            cnt = B * tiles[n.name] * n.channels * 2
+            P.stats[n.name] = P.stats_all[so:so + cnt].view(B, tiles[n.name], n.channels, 2)
             so += cnt
         pooled = [n.inputs[0].channels for n in nodes if n.op == "global_pool"]
-        P.pool_scratch = torch.zeros(B * max(pooled) * 2, dtype=torch.float32, device=dev) if pooled else None
+        P.pool_scratch = (torch.zeros(B * capi.POOL_TILES * max(pooled) * 2, dtype=torch.float32, device=dev)
+                          if pooled else None)
         P.oob = torch.zeros(1, dtype=torch.int32, device=dev)
         P.bad = torch.zeros(1, dtype=torch.int32, device=dev)
         N = B * H * W
@@ -218,6 +218,9 @@ class Engine(object):
         for n in P.convs:
             hs, ws = P.spatial(n)
             P.dz[n.name] = torch.zeros((B, hs, ws, _pad(n.channels)), dtype=tdt, device=dev)
+            t = ops.in_tiles(B, hs * ws, n.channels)       # H*W slices per sample of the two backward reductions
+            P.red[n.name] = torch.zeros((B, t, n.channels, 2), dtype=torch.float32, device=dev)
+            P.dbpart[n.name] = torch.zeros((B * t, n.channels), dtype=torch.float32, device=dev)
         # gradient buffers for every tensor that a conv, the embedding or the sampler produces
         P.ps_acc = {}
         for n in net.nodes:
@@ -403,7 +406,6 @@ class Engine(object):
             ops.hnm_weights(P.ce, P.labels, int(spec["hard_negative_ratio"]), P.weight, P.loss, P.hnm_ws)
             ops.softmax_ce_bwd(P.probs, P.labels, P.weight, C, P.dy[lname][..., :C], ls)
         self.grads_flat.zero_()
-        P.red_all.zero_()
         P.reg.zero_()
         wd = float(spec["weight_decay"])
         for n in reversed(net.nodes):
@@ -431,10 +433,14 @@ class Engine(object):
                 P.d_embed = P.dy[n.name]
         # bias gradients: fold the per-sample partials of every layer in one launch
         if getattr(P, "_sum_rows_batches", None) is None:
-            P._sum_rows_batches = ops.sum_rows_batched(
-                [(P.dbpart[n.name], self.grads[n.name + "/biases"]) for n in P.convs], P.B)
+            # partial rows per layer differ (B x slices of H*W): group the layers by row count
+            groups = OrderedDict()
+            for n in P.convs:
+                groups.setdefault(P.dbpart[n.name].shape[0], []).append((P.dbpart[n.name], self.grads[n.name + "/biases"]))
+            P._sum_rows_batches = [(rows, ops.sum_rows_batched(ents, rows)) for rows, ents in groups.items()]
         else:
-            ops.replay_sum_rows(P._sum_rows_batches, P.B)
+            for rows, batches in P._sum_rows_batches:
+                ops.replay_sum_rows(batches, rows)
         if on_ready is None:
             ops.l2_add(self.params_flat[:self.n_conv_w], self.grads_flat[:self.n_conv_w], wd, P.reg, P.scratch, ls)
         if ls is not None:

@@ -102,9 +102,13 @@ int cutie_embed_bwd(const int32_t* ids, int64_t n_cells, const void* dout, int l
  * with zero padding, sgn = +1 (forward) or -1 (flip != 0: the data gradient, fed with the
  * layer's output gradient and weights packed [tap][cin][cout]).  Several segments give the
  * gradient of a tensor with several consumers in one pass (no read-modify-write).
- * stats (nullable) f32 [B][n_out][2]: += sum and sum of squares over (h,w) of the values
- * stored (caller-zeroed) - the instance-norm moments of model_framework.py:423.
+ * stats (nullable) f32 [B][stats_tiles][n_out][2]: per 256-pixel tile, the sum and sum of squares
+ * of the values stored - the instance-norm moments of model_framework.py:423 as partial sums.
+ * Tile t of a sample STORES slot t (no float atomics: reruns are bit-identical); slots the launch
+ * does not own are left alone, so the caller zeroes the array once per forward pass.  stats_tiles
+ * >= cutie_conv_stats_tiles(H, W).  The consumers below add the slots in slot order.
  */
+int cutie_conv_stats_tiles(int H, int W);
 typedef struct {
     const void* x;        /* activations view, dtype of the call                          */
     const void* w;        /* packed weights [kh*kw][n rows][cin] in the call's dtype       */
@@ -120,7 +124,7 @@ typedef struct {
 int cutie_conv_fwd(const cutie_conv_seg* segs /* host */, int n_segs,
                    int B, int H, int W, int n_out,
                    void* out, int ld_out, int out_dtype,
-                   const float* bias, int relu, float* stats,
+                   const float* bias, int relu, float* stats, int stats_tiles,
                    int dtype, cutie_stream_t stream);
 
 /* weight gradient: dw[(i*kw+j)][c][n] (= HWIO, model_framework.py:416) =
@@ -154,25 +158,32 @@ int cutie_pack_weights_batched(const cutie_pack_desc* descs, int n, int dtype, c
 /* ---------------------------------------------------------------------------------------
  * K6  instance norm, center=False scale=False, eps 1e-6, biased variance.   Replaces
  *     tf.contrib.layers.instance_norm at model_framework.py:423 and its gradient.
- * stats f32 [B][C][2] = (sum, sum of squares) over H*W as produced by cutie_conv_fwd.
+ * stats f32 [B][stats_tiles][C][2] = partial (sum, sum of squares) over H*W as produced by
+ * cutie_conv_fwd or cutie_in_stats; every consumer adds the slots of a (b, c) in slot order.
  *   apply:     y = (a - mean) * rsqrt(var + eps)
- *   bwd_stats: red[b][c] = (sum dy, sum dy*xhat)           (caller-zeroed, f32 [B][C][2])
- *   bwd_apply: dz = [a > 0] * inv * (dy - red0/HW - xhat*red1/HW);  dbias_part[b][c] += sum_hw dz
+ *   bwd_stats: red[b][t][c] = (sum dy, sum dy*xhat) over the t-th of red_tiles slices of H*W
+ *   bwd_apply: dz = [a > 0] * inv * (dy - red0/HW - xhat*red1/HW);  dbias_part[b*dbias_tiles + t][c]
+ *              = sum of dz over the t-th slice of H*W
  *              (relu = 1 applies the ReLU mask of model_framework.py:173, relu = 2 the sigmoid
- *              derivative a*(1-a) of :175, 0 neither; dbias_part f32
- *              [B][C], caller-zeroed, nullable; cutie_sum_rows folds it over b into d(biases)
- *              in a fixed order)
+ *              derivative a*(1-a) of :175, 0 neither; dbias_part f32 [B*dbias_tiles][C], nullable;
+ *              cutie_sum_rows folds its B*dbias_tiles rows into d(biases) in a fixed order)
+ * Every producer STORES its slot (nothing to zero, no float atomics).  The *_tiles of an OUTPUT is the
+ * number of workgroups per sample the kernel runs with: cutie_in_tiles(B, HW, C) is the count that
+ * keeps the chip busy; 1 is valid and slow.
  */
+int cutie_in_tiles(int B, int HW, int C);
 int cutie_in_stats(const void* a, int ld_a, int a_dtype, int B, int HW, int C, float* stats,
+                   int stats_tiles, cutie_stream_t stream);
+int cutie_in_apply(const void* a, int ld_a, int a_dtype, const float* stats, int stats_tiles,
+                   float eps, void* y, int ld_y, int y_dtype, int B, int HW, int C,
                    cutie_stream_t stream);
-int cutie_in_apply(const void* a, int ld_a, int a_dtype, const float* stats, float eps,
-                   void* y, int ld_y, int y_dtype, int B, int HW, int C, cutie_stream_t stream);
 int cutie_in_bwd_stats(const void* dy, int ld_dy, int dy_dtype, const void* a, int ld_a,
-                       int a_dtype, const float* stats, float eps, float* red,
-                       int B, int HW, int C, cutie_stream_t stream);
+                       int a_dtype, const float* stats, int stats_tiles, float eps, float* red,
+                       int red_tiles, int B, int HW, int C, cutie_stream_t stream);
 int cutie_in_bwd_apply(const void* dy, int ld_dy, int dy_dtype, const void* a, int ld_a,
-                       int a_dtype, const float* stats, float eps, const float* red, int relu,
-                       void* dz, int ld_dz, int dz_dtype, float* dbias_part,
+                       int a_dtype, const float* stats, int stats_tiles, float eps,
+                       const float* red, int red_tiles, int relu,
+                       void* dz, int ld_dz, int dz_dtype, float* dbias_part, int dbias_tiles,
                        int B, int HW, int C, cutie_stream_t stream);
 /* out[c] (+)= sum over b of part[b][c] */
 int cutie_sum_rows(const float* part, int B, int C, float* out, int accumulate, cutie_stream_t stream);
@@ -187,9 +198,11 @@ int cutie_sum_rows_batched(const cutie_sum_rows_desc* descs, int n, int B, int a
 
 /* K8  Model.global_pool, model_framework.py:309-315: spatial mean broadcast back to HxW
  * (reduce_mean + nearest-neighbour resize), written into a channel slice.
- * scratch (nullable): B*C*2 floats, clobbered; with it the sums are taken by the wide-grid
- * statistics pass (float atomics) and the broadcast is a pure store pass; without it one
- * workgroup per (sample, 128 channels) does both in a fixed order. */
+ * scratch (nullable): B*CUTIE_POOL_TILES*C*2 floats, clobbered; with it the sums are taken by
+ * the wide-grid statistics pass (slot partials) and the broadcast is a store pass that adds the
+ * slots in order; without it one workgroup per (sample, 128 channels) does both.  Both orders
+ * are fixed: reruns are bit-identical. */
+#define CUTIE_POOL_TILES 32
 int cutie_spatial_mean_bcast(const void* x, int ld_x, int x_dtype, void* out, int ld_out,
                              int out_dtype, int B, int HW, int C, float* scratch,
                              cutie_stream_t stream);

@@ -187,7 +187,7 @@ def test_conv_fwd(ops, dt, case):
     wf, _ = ops.pack_weights(w.to(DEV), cdt)
     ld_out = cout + 8
     out = torch.full((B, H, W, ld_out), 3.0, dtype=torch.float32, device=DEV)
-    stats = torch.zeros((B, cout, 2), dtype=torch.float32, device=DEV)
+    stats = torch.zeros((B, ops.conv_stats_tiles(H, W) + 1, cout, 2), dtype=torch.float32, device=DEV)   # per-tile slots
     xd = torch.zeros((B, H, W, cin + 64), dtype=tdt, device=DEV)   # read through a channel-slice view
     xd[..., 32:32 + cin] = x.to(DEV)
     ops.conv_fwd([dict(x=xd[..., 32:32 + cin], w=wf, cin=cin, kh=kh, kw=kw, dil=dil)], out[..., :cout], cout,
@@ -197,7 +197,13 @@ def test_conv_fwd(ops, dt, case):
     assert relerr(out[..., :cout], ref_a) < tol
     assert torch.all(out[..., cout:] == 3.0)
     ref_s = torch.stack([ref_a.sum(dim=(1, 2)), (ref_a ** 2).sum(dim=(1, 2))], dim=-1)
-    assert relerr(stats, ref_s) < (1e-4 if dt == "f32" else 2e-3)
+    assert relerr(stats.sum(dim=1), ref_s) < (1e-4 if dt == "f32" else 2e-3)
+    assert float(stats[:, -1].abs().max()) == 0.0           # a slot no tile owns stays untouched
+    # no float atomics: a second launch reproduces output and moments bit for bit
+    out2, stats2 = torch.full_like(out, 3.0), torch.zeros_like(stats)
+    ops.conv_fwd([dict(x=xd[..., 32:32 + cin], w=wf, cin=cin, kh=kh, kw=kw, dil=dil)], out2[..., :cout], cout,
+                 bias=bias.to(DEV), relu=True, stats=stats2)
+    assert torch.equal(out, out2) and torch.equal(stats, stats2)
 
 
 @pytest.mark.parametrize("dt", ["f32", "bf16", "f16"])
@@ -247,7 +253,7 @@ def test_conv_wide_16bit(ops, case, dt):
     wf, _ = ops.pack_weights(w.to(DEV), CDT[dt])
     ld_out = cout + 8
     out = torch.full((B, H, W, ld_out), 3.0, dtype=tdt, device=DEV)
-    stats = torch.zeros((B, cout, 2), dtype=torch.float32, device=DEV)
+    stats = torch.zeros((B, ops.conv_stats_tiles(H, W) + 1, cout, 2), dtype=torch.float32, device=DEV)   # per-tile slots
     xd = torch.zeros((B, H, W, cin + 64), dtype=tdt, device=DEV)
     xd[..., 32:32 + cin] = x.to(DEV)
     ops.conv_fwd([dict(x=xd[..., 32:32 + cin], w=wf, cin=cin, kh=kh, kw=kw, dil=dil)], out[..., :cout], cout,
@@ -258,7 +264,11 @@ def test_conv_wide_16bit(ops, case, dt):
     assert (out[..., :cout].float().cpu() - ref_a.float().to(tdt).float()).abs().max() < (0.009 if dt == "f16" else 0.07)
     assert torch.all(out[..., cout:] == 3.0)
     ref_s = torch.stack([ref_a.sum(dim=(1, 2)), (ref_a ** 2).sum(dim=(1, 2))], dim=-1)
-    assert relerr(stats, ref_s) < 2e-3
+    assert relerr(stats.sum(dim=1), ref_s) < 2e-3
+    out2, stats2 = torch.full_like(out, 3.0), torch.zeros_like(stats)
+    ops.conv_fwd([dict(x=xd[..., 32:32 + cin], w=wf, cin=cin, kh=kh, kw=kw, dil=dil)], out2[..., :cout], cout,
+                 bias=bias.to(DEV), relu=True, stats=stats2)
+    assert torch.equal(out, out2) and torch.equal(stats, stats2)
 
 
 @pytest.mark.parametrize("dt", ["bf16", "f16"])
@@ -363,10 +373,10 @@ def test_instance_norm_fwd_bwd(ops, dt, C):
     ld = (C + 3) // 4 * 4 + 4
     ad = torch.zeros((B, H, W, ld), dtype=tdt, device=DEV)
     ad[..., :C] = a.to(DEV)
-    stats = torch.zeros((B, C, 2), dtype=torch.float32, device=DEV)
+    stats = torch.full((B, 5, C, 2), 7.0, dtype=torch.float32, device=DEV)      # 5 slices of H*W, every slot written
     ops.in_stats(ad[..., :C], stats)
     ref_s = torch.stack([a.double().sum(dim=(1, 2)), (a.double() ** 2).sum(dim=(1, 2))], dim=-1)
-    assert relerr(stats, ref_s) < 1e-5
+    assert relerr(stats.sum(dim=1), ref_s) < 1e-5
     y = torch.full((B, H, W, ld), 5.0, dtype=torch.float32, device=DEV)
     ops.in_apply(ad[..., :C], stats, y[..., :C])
     assert relerr(y[..., :C], y_ref) < 1e-4
@@ -375,10 +385,10 @@ def test_instance_norm_fwd_bwd(ops, dt, C):
     # backward through IN and the ReLU mask
     (y_ref * dy.double()).sum().backward()
     da_ref = a64.grad * (a.double() > 0)
-    red = torch.zeros((B, C, 2), dtype=torch.float32, device=DEV)
+    red = torch.full((B, 3, C, 2), 7.0, dtype=torch.float32, device=DEV)
     ops.in_bwd_stats(dy.to(DEV), ad[..., :C], stats, red)
     dz = torch.zeros((B, H, W, ld), dtype=tdt, device=DEV)
-    dbp = torch.zeros((B, C), dtype=torch.float32, device=DEV)
+    dbp = torch.full((B * 4, C), 7.0, dtype=torch.float32, device=DEV)
     db = torch.full((C,), 4.0, dtype=torch.float32, device=DEV)
     ops.in_bwd_apply(dy.to(DEV), ad[..., :C], stats, red, dz[..., :C], dbias_part=dbp, relu=True)
     ops.sum_rows(dbp, db)
@@ -394,7 +404,7 @@ def test_spatial_mean_bcast(ops, dt, C, with_scratch):
     tdt = TDT[dt]
     x = (torch.randn((3, 10, 12, C), generator=g) + 0.5).to(tdt)
     out = torch.zeros((3, 10, 12, 3 * C + C), dtype=tdt, device=DEV)
-    scratch = torch.full((3 * C * 2 + 5,), 9.0, dtype=torch.float32, device=DEV) if with_scratch else None
+    scratch = torch.full((3 * 32 * C * 2 + 5,), 9.0, dtype=torch.float32, device=DEV) if with_scratch else None   # CUTIE_POOL_TILES
     ops.spatial_mean_bcast(x.to(DEV), out[..., 3 * C:], scratch)
     assert relerr(out[..., 3 * C:], co.global_pool(x.double())) < {"f32": 1e-5, "bf16": 4e-3, "f16": 5e-4}[dt]
     assert float(out[..., :3 * C].abs().max()) == 0.0
