@@ -28,6 +28,16 @@ struct ConvParams {
     int stats_tiles;
     int TH, TWB, tiles_h, tiles_w, n_tiles_n;
     int a_bytes;  // LDS bytes reserved for the A patch
+    // Instance-norm backward reduction fused into a data-gradient launch (conv_wide only; nullable):
+    // `out` is dy of a layer whose forward pre-norm activation is bw_a with moments bw_stats; tile t
+    // of a sample STORES (sum dy, sum dy * xhat) over its pixels into slot t of bw_red.
+    const char* bw_a;
+    int bw_ld_a;
+    const float* bw_stats;   // [B][bw_stats_tiles][n_out][2]
+    int bw_stats_tiles;
+    float bw_eps;
+    float* bw_red;           // [B][bw_red_tiles][n_out][2]
+    int bw_red_tiles;
 };
 
 template <int DT> struct Traits;

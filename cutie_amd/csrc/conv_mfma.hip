@@ -739,9 +739,21 @@ extern "C" int cutie_conv_stats_tiles(int H, int W) {
     return (int)(g > w ? g : w);
 }
 
-extern "C" int cutie_conv_fwd(const cutie_conv_seg* segs, int n_segs, int B, int H, int W, int n_out, void* out,
-                              int ld_out, int out_dtype, const float* bias, int relu, float* stats, int stats_tiles,
-                              int dtype, cutie_stream_t stream_) {
+namespace {
+struct NormBwd {      // the reduction of cutie_in_bwd_stats, asked of a data-gradient launch
+    const void* a;
+    int ld_a, a_dtype;
+    const float* stats;
+    int stats_tiles;
+    float eps;
+    float* red;
+    int red_tiles;
+};
+}  // namespace
+
+static int conv_fwd_impl(const cutie_conv_seg* segs, int n_segs, int B, int H, int W, int n_out, void* out,
+                         int ld_out, int out_dtype, const float* bias, int relu, float* stats, int stats_tiles,
+                         int dtype, const NormBwd* nb, cutie_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     CUTIE_CHECK_ARG(segs && n_segs >= 1 && n_segs <= CUTIE_MAX_SEGS, "conv_fwd: n_segs=%d (1..%d)", n_segs, CUTIE_MAX_SEGS);
     CUTIE_CHECK_ARG(B >= 0 && H >= 1 && W >= 1 && n_out >= 1 && ld_out >= n_out, "conv_fwd: bad sizes B=%d H=%d W=%d n_out=%d ld_out=%d",
@@ -757,6 +769,7 @@ extern "C" int cutie_conv_fwd(const cutie_conv_seg* segs, int n_segs, int B, int
 
     ConvParams p;
     p.nseg = n_segs;
+    p.bw_a = nullptr; p.bw_ld_a = 0; p.bw_stats = nullptr; p.bw_stats_tiles = 0; p.bw_eps = 0.f; p.bw_red = nullptr; p.bw_red_tiles = 0;
     int twb, th_g;
     generic_tiling(W, th_g, twb);
     p.TWB = twb;
@@ -811,19 +824,59 @@ extern "C" int cutie_conv_fwd(const cutie_conv_seg* segs, int n_segs, int B, int
         q.tiles_h = (int)cutie::cdiv(H, th);
         q.tiles_w = (int)cutie::cdiv(W, tcb * 16);
         q.n_tiles_n = n_out / bn;
-        if ((long long)B * q.tiles_h * q.tiles_w * q.n_tiles_n < (1ll << 31)) return cutie::launch_conv_wide(q, dtype, bn, stream);
+        if ((long long)B * q.tiles_h * q.tiles_w * q.n_tiles_n < (1ll << 31)) {
+            static const bool fuse_on = !(getenv("CUTIE_FUSE_NORM_BWD") && atoi(getenv("CUTIE_FUSE_NORM_BWD")) == 0);
+            const bool fuse = nb && fuse_on && nb->a_dtype == dtype && (nb->ld_a * 2) % 16 == 0 && cutie::aligned16(nb->a) &&
+                              q.tiles_h * q.tiles_w <= nb->red_tiles;
+            if (fuse) {
+                q.bw_a = (const char*)nb->a; q.bw_ld_a = nb->ld_a; q.bw_stats = nb->stats; q.bw_stats_tiles = nb->stats_tiles;
+                q.bw_eps = nb->eps; q.bw_red = nb->red; q.bw_red_tiles = nb->red_tiles;
+            }
+            const int rc = cutie::launch_conv_wide(q, dtype, bn, stream);
+            if (rc != CUTIE_OK || fuse || !nb) return rc;
+            return cutie_in_bwd_stats(out, ld_out, out_dtype, nb->a, nb->ld_a, nb->a_dtype, nb->stats, nb->stats_tiles, nb->eps,
+                                      nb->red, nb->red_tiles, B, H * W, n_out, stream_);
+        }
     }
+    int rc;
     if (dtype == CUTIE_BF16) {
-        if (out_dtype == CUTIE_BF16) return launch_conv<CUTIE_BF16, CUTIE_BF16>(p, lds, stream);
-        return launch_conv<CUTIE_BF16, CUTIE_F32>(p, lds, stream);
+        rc = out_dtype == CUTIE_BF16 ? launch_conv<CUTIE_BF16, CUTIE_BF16>(p, lds, stream) : launch_conv<CUTIE_BF16, CUTIE_F32>(p, lds, stream);
+    } else if (dtype == CUTIE_F16) {
+        rc = out_dtype == CUTIE_F16 ? launch_conv<CUTIE_F16, CUTIE_F16>(p, lds, stream) : launch_conv<CUTIE_F16, CUTIE_F32>(p, lds, stream);
+    } else if (out_dtype == CUTIE_BF16) {
+        rc = launch_conv<CUTIE_F32, CUTIE_BF16>(p, lds, stream);
+    } else if (out_dtype == CUTIE_F16) {
+        rc = launch_conv<CUTIE_F32, CUTIE_F16>(p, lds, stream);
+    } else {
+        rc = launch_conv<CUTIE_F32, CUTIE_F32>(p, lds, stream);
     }
-    if (dtype == CUTIE_F16) {
-        if (out_dtype == CUTIE_F16) return launch_conv<CUTIE_F16, CUTIE_F16>(p, lds, stream);
-        return launch_conv<CUTIE_F16, CUTIE_F32>(p, lds, stream);
-    }
-    if (out_dtype == CUTIE_BF16) return launch_conv<CUTIE_F32, CUTIE_BF16>(p, lds, stream);
-    if (out_dtype == CUTIE_F16) return launch_conv<CUTIE_F32, CUTIE_F16>(p, lds, stream);
-    return launch_conv<CUTIE_F32, CUTIE_F32>(p, lds, stream);
+    if (rc != CUTIE_OK || !nb) return rc;
+    // kernels without the fused reduction: the separate pass, into the same slots' array
+    return cutie_in_bwd_stats(out, ld_out, out_dtype, nb->a, nb->ld_a, nb->a_dtype, nb->stats, nb->stats_tiles, nb->eps, nb->red,
+                              nb->red_tiles, B, H * W, n_out, stream_);
+}
+
+extern "C" int cutie_conv_fwd(const cutie_conv_seg* segs, int n_segs, int B, int H, int W, int n_out, void* out,
+                              int ld_out, int out_dtype, const float* bias, int relu, float* stats, int stats_tiles,
+                              int dtype, cutie_stream_t stream_) {
+    return conv_fwd_impl(segs, n_segs, B, H, W, n_out, out, ld_out, out_dtype, bias, relu, stats, stats_tiles, dtype, nullptr,
+                         stream_);
+}
+
+extern "C" int cutie_conv_dgrad_in_stats(const cutie_conv_seg* segs, int n_segs, int B, int H, int W, int n_out, void* out,
+                                         int ld_out, int out_dtype, const void* a, int ld_a, int a_dtype, const float* stats,
+                                         int stats_tiles, float eps, float* red, int red_tiles, int dtype,
+                                         cutie_stream_t stream_) {
+    CUTIE_CHECK_ARG(B >= 0 && H >= 1 && W >= 1 && n_out >= 1, "conv_dgrad_in_stats: bad sizes");
+    if (B == 0) return CUTIE_OK;
+    CUTIE_CHECK_ARG(a && stats && red && ld_a >= n_out, "conv_dgrad_in_stats: null pointer or ld_a < n_out");
+    CUTIE_CHECK_ARG(stats_tiles >= 1 && red_tiles >= cutie_conv_stats_tiles(H, W) && red_tiles <= 65535,
+                    "conv_dgrad_in_stats: stats_tiles=%d, red_tiles=%d (>= cutie_conv_stats_tiles(%d, %d) = %d)", stats_tiles,
+                    red_tiles, H, W, cutie_conv_stats_tiles(H, W));
+    CUTIE_CHECK_ARG((reinterpret_cast<uintptr_t>(stats) & 7) == 0 && (reinterpret_cast<uintptr_t>(red) & 7) == 0,
+                    "conv_dgrad_in_stats: stats and red must be 8-byte aligned");
+    const NormBwd nb = {a, ld_a, a_dtype, stats, stats_tiles, eps, red, red_tiles};
+    return conv_fwd_impl(segs, n_segs, B, H, W, n_out, out, ld_out, out_dtype, nullptr, 0, nullptr, 0, dtype, &nb, stream_);
 }
 
 extern "C" size_t cutie_conv_wgrad_workspace_bytes(int B, int H, int W, int cin, int cout, int kh, int kw) {

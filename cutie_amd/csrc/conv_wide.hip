@@ -33,10 +33,27 @@ template <int BN> struct Shape {
     static constexpr int NP = 4 + NB;           // pieces per wave and step (A: always 4)
     static constexpr int BBUF = BN * 128;
     static constexpr int WSUM = 256 * BN * 2;   // per-wave instance-norm partials sit behind the staged output tile
-    static constexpr int LDS = (CW_B0 + 2 * BBUF > WSUM + WM * BN * 8) ? CW_B0 + 2 * BBUF : WSUM + WM * BN * 8;
+    static constexpr int TAB = WSUM + WM * BN * 8;   // [2][BN] f32 mean, inv of the fused norm-backward reduction
+    static constexpr int LDS = (CW_B0 + 2 * BBUF > TAB + 2 * BN * 4) ? CW_B0 + 2 * BBUF : TAB + 2 * BN * 4;
 };
 
-// bias, ReLU, instance-norm moments, LDS-staged coalesced store of a 256-pixel x BN-channel tile
+template <int DT> __device__ __forceinline__ void unpack8(const uint4& u, float* v) {
+    if constexpr (DT == CUTIE_BF16) {
+        v[0] = __uint_as_float(u.x << 16); v[1] = __uint_as_float(u.x & 0xffff0000u);
+        v[2] = __uint_as_float(u.y << 16); v[3] = __uint_as_float(u.y & 0xffff0000u);
+        v[4] = __uint_as_float(u.z << 16); v[5] = __uint_as_float(u.z & 0xffff0000u);
+        v[6] = __uint_as_float(u.w << 16); v[7] = __uint_as_float(u.w & 0xffff0000u);
+    } else {
+        const half8_t h = __builtin_bit_cast(half8_t, u);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = static_cast<float>(h[i]);
+    }
+}
+
+// bias, ReLU, instance-norm moments, LDS-staged coalesced store of a 256-pixel x BN-channel tile.
+// With p.bw_a (data gradient of an instance-normalised layer) the store pass also takes this tile's share of
+// (sum dy, sum dy * xhat) from the ROUNDED dy it stores and the layer's forward activation, so that
+// cutie_in_bwd_apply can follow without a separate reduction pass over dy and a.
 template <int DT, int BN>
 __device__ __forceinline__ void conv_wide_epilogue(const ConvParams& p, float4_t (&acc)[Shape<BN>::MB][4], char* smem, int b,
                                                    int tile, int h0, int w0, int n0) {
@@ -47,10 +64,49 @@ __device__ __forceinline__ void conv_wide_epilogue(const ConvParams& p, float4_t
     const int wm = wave / S::WN, wn = wave % S::WN;
     const int li = lane & 15, lg = lane >> 4;
     const int H = p.H, W = p.W, TCB = p.TWB, n_out = p.n_out;
-    __syncthreads();
     typedef typename elem<DT>::type TO;
+    constexpr int PPR = BN / 8;          // 16-byte pieces per pixel row
+    constexpr int RG = CW_NT / PPR;      // pixel rows side by side in the store pass: 16 / 32 / 64
+    constexpr int IT = 256 / RG;         // store iterations per lane: 16 / 8 / 4
+    const int pc = tid % PPR, rg = tid / PPR;
+    const bool bw = p.bw_a != nullptr;
+
+    // the forward activation pieces and the forward moments are requested first: their latency passes
+    // under the staging of the accumulators
+    uint4 av[IT];
+    float fs = 0.f, fss = 0.f;
+    if (bw) {
+#pragma unroll
+        for (int k = 0; k < IT; ++k) {
+            const int ml = rg + k * RG;
+            const int mb = ml >> 4;
+            const int h = h0 + mb / TCB, w = w0 + (mb % TCB) * 16 + (ml & 15);
+            av[k] = make_uint4(0u, 0u, 0u, 0u);
+            if (h < H && w < W && n0 + pc * 8 < n_out)
+                av[k] = *reinterpret_cast<const uint4*>(reinterpret_cast<const TO*>(p.bw_a) +
+                                                        ((long long)(b * H + h) * W + w) * p.bw_ld_a + n0 + pc * 8);
+        }
+        if (tid < BN && n0 + tid < n_out) {
+            // the slots in slot order, exactly as norm.hip's fold takes them
+#pragma unroll 4
+            for (int t = 0; t < p.bw_stats_tiles; ++t) {
+                const float2 v = *reinterpret_cast<const float2*>(p.bw_stats + (((long long)b * p.bw_stats_tiles + t) * n_out + n0 + tid) * 2);
+                fs += v.x;
+                fss += v.y;
+            }
+        }
+    }
+    __syncthreads();
     TO* Cs = reinterpret_cast<TO*>(smem);  // [256 pixels][BN channels]
     float2* wsum = reinterpret_cast<float2*>(smem + S::WSUM);   // [WM][BN]
+    float* tab = reinterpret_cast<float*>(smem + S::TAB);       // [2][BN]
+    if (bw && tid < BN) {
+        const float inv_n = 1.f / (float)(H * W);
+        const float mean = fs * inv_n;
+        const float var = fmaxf(fss * inv_n - mean * mean, 0.f);
+        tab[tid] = mean;
+        tab[BN + tid] = rsqrtf(var + p.bw_eps);
+    }
 #pragma unroll
     for (int n = 0; n < 4; ++n) {
         const int cl = wn * 64 + n * 16 + li;
@@ -91,16 +147,53 @@ __device__ __forceinline__ void conv_wide_epilogue(const ConvParams& p, float4_t
         }
         *reinterpret_cast<float2*>(p.stats + (((long long)b * p.stats_tiles + tile) * n_out + n0 + tid) * 2) = make_float2(s1, s2);
     }
-    constexpr int PPR = BN / 8;                                   // 16-byte pieces per pixel row
-    for (int idx = tid; idx < 256 * PPR; idx += CW_NT) {
-        const int ml = idx / PPR, pc = idx % PPR;
+    const int col = n0 + pc * 8;
+    float mean8[8], inv8[8], g1[8], g2[8];
+    if (bw) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            mean8[e] = tab[pc * 8 + e];
+            inv8[e] = tab[BN + pc * 8 + e];
+            g1[e] = 0.f;
+            g2[e] = 0.f;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < IT; ++k) {
+        const int ml = rg + k * RG;
         const int mb = ml >> 4;
         const int h = h0 + mb / TCB, w = w0 + (mb % TCB) * 16 + (ml & 15);
-        const int col = n0 + pc * 8;
         if (h < H && w < W && col < n_out) {
+            const uint4 gv = *reinterpret_cast<const uint4*>(Cs + ml * BN + pc * 8);
             TO* dst = reinterpret_cast<TO*>(p.out) + ((long long)(b * H + h) * W + w) * p.ld_out + col;
-            *reinterpret_cast<uint4*>(dst) = *reinterpret_cast<const uint4*>(Cs + ml * BN + pc * 8);
+            *reinterpret_cast<uint4*>(dst) = gv;
+            if (bw) {
+                float g[8], x[8];
+                unpack8<DT>(gv, g);
+                unpack8<DT>(av[k], x);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    g1[e] += g[e];
+                    g2[e] += g[e] * ((x[e] - mean8[e]) * inv8[e]);
+                }
+            }
         }
+    }
+    if (!bw) return;
+    __syncthreads();                     // the staged tile has been read: its LDS becomes the reduction buffer
+    float2* rb = reinterpret_cast<float2*>(smem);      // [RG][BN]
+#pragma unroll
+    for (int e = 0; e < 8; ++e) rb[rg * BN + pc * 8 + e] = make_float2(g1[e], g2[e]);
+    __syncthreads();
+    if (tid < BN && n0 + tid < n_out) {
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll 4
+        for (int r = 0; r < RG; ++r) {   // fixed order
+            const float2 v = rb[r * BN + tid];
+            s1 += v.x;
+            s2 += v.y;
+        }
+        *reinterpret_cast<float2*>(p.bw_red + (((long long)b * p.bw_red_tiles + tile) * n_out + n0 + tid) * 2) = make_float2(s1, s2);
     }
 }
 

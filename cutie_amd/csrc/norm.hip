@@ -94,6 +94,7 @@ __device__ __forceinline__ Map make_map(int HW, int CV) {
 __device__ __forceinline__ void sum_tiles(const float* p, int b, int T, int C, int c, float& s0, float& s1) {
     s0 = 0.f;
     s1 = 0.f;
+#pragma unroll 4
     for (int t = 0; t < T; ++t) {
         const float2 v = *reinterpret_cast<const float2*>(p + (((int64_t)b * T + t) * C + c) * 2);
         s0 += v.x;
@@ -101,13 +102,24 @@ __device__ __forceinline__ void sum_tiles(const float* p, int b, int T, int C, i
     }
 }
 
-__device__ __forceinline__ void mean_inv(const float* stats, int b, int T, int C, int c, float inv_n, float eps,
-                                         float& mean, float& inv) {
-    float s, ss;
-    sum_tiles(stats, b, T, C, c, s, ss);
-    mean = s * inv_n;
-    const float var = fmaxf(ss * inv_n - mean * mean, 0.f);
-    inv = rsqrtf(var + eps);
+// Workgroup-wide fold of the T slots of sample b into LDS tables (one channel per lane, coalesced float2 reads):
+// every lane of a kernel then picks its VEC channels out of LDS instead of walking T slots per channel itself.
+// MODE 0: t0 = sum0, t1 = sum1;  MODE 1: t0 = mean, t1 = 1/sigma (the arithmetic of mean_inv).
+// The caller synchronises before reading the tables.
+template <int MODE>
+__device__ __forceinline__ void fold_slots(const float* p, int b, int T, int C, float inv_n, float eps, float* t0, float* t1) {
+    for (int c = threadIdx.x; c < C; c += 256) {
+        float s, ss;
+        sum_tiles(p, b, T, C, c, s, ss);
+        if (MODE == 1) {
+            const float mean = s * inv_n;
+            const float var = fmaxf(ss * inv_n - mean * mean, 0.f);
+            s = mean;
+            ss = rsqrtf(var + eps);
+        }
+        t0[c] = s;
+        t1[c] = ss;
+    }
 }
 
 // red[NRED][256][VEC] in LDS -> sum over the side-by-side rows (fixed order) -> *dst(c, k) = sum
@@ -148,13 +160,16 @@ template <int VEC, typename TA, typename TY>
 __global__ __launch_bounds__(256) void in_apply_kernel(const TA* __restrict__ a, int ld_a,
                                                        const float* __restrict__ stats, int st, float eps,
                                                        TY* __restrict__ y, int ld_y, int HW, int C) {
+    __shared__ float tab[2][256 * VEC];
     const int CV = C / VEC;
     const Map m = make_map(HW, CV);
-    if (!m.active) return;
     const float inv_n = 1.f / (float)HW;
+    fold_slots<1>(stats, m.b, st, C, inv_n, eps, tab[0], tab[1]);
+    __syncthreads();
+    if (!m.active) return;
     float mean[VEC], inv[VEC];
 #pragma unroll
-    for (int e = 0; e < VEC; ++e) mean_inv(stats, m.b, st, C, m.cl * VEC + e, inv_n, eps, mean[e], inv[e]);
+    for (int e = 0; e < VEC; ++e) { mean[e] = tab[0][m.cl * VEC + e]; inv[e] = tab[1][m.cl * VEC + e]; }
     for (int hw = m.hw0 + m.sub; hw < m.hw1; hw += m.rows_par) {
         const int64_t row = (int64_t)m.b * HW + hw;
         vecf<VEC> x = loadv<VEC>(a + row * ld_a + m.cl * VEC);
@@ -170,14 +185,16 @@ __global__ __launch_bounds__(256) void in_bwd_stats_kernel(const TD* __restrict_
                                                            const float* __restrict__ stats, int st, float eps,
                                                            float* __restrict__ redout, int HW, int C) {
     __shared__ float red[2][256][VEC];
+    __shared__ float tab[2][256 * VEC];
     const int CV = C / VEC;
     const Map m = make_map(HW, CV);
+    fold_slots<1>(stats, m.b, st, C, 1.f / (float)HW, eps, tab[0], tab[1]);
+    __syncthreads();
     float s1[VEC] = {}, s2[VEC] = {};
     if (m.active) {
-        const float inv_n = 1.f / (float)HW;
         float mean[VEC], inv[VEC];
 #pragma unroll
-        for (int e = 0; e < VEC; ++e) mean_inv(stats, m.b, st, C, m.cl * VEC + e, inv_n, eps, mean[e], inv[e]);
+        for (int e = 0; e < VEC; ++e) { mean[e] = tab[0][m.cl * VEC + e]; inv[e] = tab[1][m.cl * VEC + e]; }
 #pragma unroll 4
         for (int hw = m.hw0 + m.sub; hw < m.hw1; hw += m.rows_par) {
             const int64_t row = (int64_t)m.b * HW + hw;
@@ -204,19 +221,23 @@ __global__ __launch_bounds__(256) void in_bwd_apply_kernel(const TD* __restrict_
                                                            TZ* __restrict__ dz, int ld_dz,
                                                            float* __restrict__ dbias, int HW, int C) {
     __shared__ float red[1][256][VEC];
+    __shared__ float tab[4][256 * VEC];
     const int CV = C / VEC;
     const Map m = make_map(HW, CV);
+    const float inv_n = 1.f / (float)HW;
+    fold_slots<1>(stats, m.b, st, C, inv_n, eps, tab[0], tab[1]);
+    fold_slots<0>(redin, m.b, rt, C, inv_n, eps, tab[2], tab[3]);
+    __syncthreads();
     float sb[VEC] = {};
     if (m.active) {
-        const float inv_n = 1.f / (float)HW;
         float mean[VEC], inv[VEC], m1[VEC], m2[VEC];
 #pragma unroll
         for (int e = 0; e < VEC; ++e) {
             const int c = m.cl * VEC + e;
-            mean_inv(stats, m.b, st, C, c, inv_n, eps, mean[e], inv[e]);
-            sum_tiles(redin, m.b, rt, C, c, m1[e], m2[e]);
-            m1[e] *= inv_n;
-            m2[e] *= inv_n;
+            mean[e] = tab[0][c];
+            inv[e] = tab[1][c];
+            m1[e] = tab[2][c] * inv_n;
+            m2[e] = tab[3][c] * inv_n;
         }
         for (int hw = m.hw0 + m.sub; hw < m.hw1; hw += m.rows_par) {
             const int64_t row = (int64_t)m.b * HW + hw;
@@ -290,19 +311,18 @@ __global__ __launch_bounds__(256) void mean_bcast_kernel(const TX* __restrict__ 
 template <int VEC, typename TO>
 __global__ __launch_bounds__(256) void bcast_mean_kernel(const float* __restrict__ sums, int st, TO* __restrict__ out,
                                                          int ld_out, int HW, int C, int rows_per_wg) {
+    __shared__ float tab[2][256 * VEC];
     const int CV = C / VEC;
     const int b = blockIdx.y;
     const int rows_par = 256 / CV;
     const int cl = threadIdx.x % CV, sub = threadIdx.x / CV;
+    fold_slots<0>(sums, b, st, C, 0.f, 0.f, tab[0], tab[1]);
+    __syncthreads();
     if (sub >= rows_par) return;
     vecf<VEC> mv;
     const float inv = 1.f / (float)HW;
 #pragma unroll
-    for (int e = 0; e < VEC; ++e) {
-        float s0, s1;
-        sum_tiles(sums, b, st, C, cl * VEC + e, s0, s1);
-        mv.v[e] = s0 * inv;
-    }
+    for (int e = 0; e < VEC; ++e) mv.v[e] = tab[0][cl * VEC + e] * inv;
     const int r0 = blockIdx.x * rows_per_wg;
     const int r1 = min(HW, r0 + rows_per_wg);
     for (int hw = r0 + sub; hw < r1; hw += rows_par) storev<VEC>(out + ((int64_t)b * HW + hw) * ld_out + cl * VEC, mv);

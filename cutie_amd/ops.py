@@ -126,10 +126,12 @@ def replay_sum_rows(batches, B, accumulate=False):
 ACTIVATION_CODE = {None: 0, False: 0, "none": 0, True: 1, "relu": 1, "sigmoid": 2}
 
 
-def conv_fwd(segs, out, n_out, bias=None, relu=False, stats=None):
+def conv_fwd(segs, out, n_out, bias=None, relu=False, stats=None, norm_bwd=None):
     """segs: list of dict(x=[B,H,W,>=cin] view, w=packed [taps, n_rows, cin], cin, kh, kw, dil, flip,
     n_off=row offset into w).  out: [B,H,W,>=n_out] view.  stats: zeroed f32 [B, T, n_out, 2] with
-    T >= conv_stats_tiles(H, W): per-tile partial moments (sum over T for the totals)."""
+    T >= conv_stats_tiles(H, W): per-tile partial moments (sum over T for the totals).
+    norm_bwd = (a, stats, red) makes this a data-gradient launch that also leaves in_bwd_stats(out, a, stats)
+    in `red` (f32 [B, T, n_out, 2], zeroed once by the caller; cutie_conv_dgrad_in_stats)."""
     B, H, W = out.shape[0], out.shape[1], out.shape[2]
     arr = (ConvSeg * len(segs))()
     dt = None
@@ -155,6 +157,14 @@ def conv_fwd(segs, out, n_out, bias=None, relu=False, stats=None):
         arr[i].cin = cin
         arr[i].kh, arr[i].kw, arr[i].dil = s["kh"], s["kw"], s["dil"]
         arr[i].flip = 1 if s.get("flip") else 0
+    if norm_bwd is not None:
+        if bias is not None or ACTIVATION_CODE[relu] or stats is not None:
+            raise capi.CutieError("conv_fwd: norm_bwd goes with a plain data gradient (no bias / activation / stats)")
+        a, fstats, red = norm_bwd
+        call("cutie_conv_dgrad_in_stats", arr, len(segs), B, H, W, n_out, ptr(out), ld_of(out), dt_of(out), ptr(a),
+             ld_of(a), dt_of(a), ptr(fstats), _tiles(fstats, B, n_out, True), IN_EPS, ptr(red),
+             _tiles(red, B, n_out, True), dt, stream())
+        return out
     call("cutie_conv_fwd", arr, len(segs), B, H, W, n_out, ptr(out), ld_of(out), dt_of(out), ptr(bias),
          ACTIVATION_CODE[relu], ptr(stats), _tiles(stats, B, n_out, True), dt, stream())
     return out

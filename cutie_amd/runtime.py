@@ -219,7 +219,10 @@ class Engine(object):
             hs, ws = P.spatial(n)
             P.dz[n.name] = torch.zeros((B, hs, ws, _pad(n.channels)), dtype=tdt, device=dev)
             t = ops.in_tiles(B, hs * ws, n.channels)       # H*W slices per sample of the two backward reductions
-            P.red[n.name] = torch.zeros((B, t, n.channels, 2), dtype=torch.float32, device=dev)
+            # (sum dy, sum dy*xhat) slots: filled by the data gradient's own epilogue (one slot per conv tile;
+            # the rest stay zero) or by in_bwd_stats (all of them)
+            P.red[n.name] = torch.zeros((B, ops.conv_stats_tiles(hs, ws), n.channels, 2), dtype=torch.float32,
+                                        device=dev)
             P.dbpart[n.name] = torch.zeros((B * t, n.channels), dtype=torch.float32, device=dev)
         # gradient buffers for every tensor that a conv, the embedding or the sampler produces
         P.ps_acc = {}
@@ -278,7 +281,8 @@ class Engine(object):
         return [c for c in P.consumers.get(name, []) if c.op == "positional_sampling" and c.inputs[0].name == name]
 
     def _backprop_into(self, P, n):
-        """dy of node n's output from everything that consumes it."""
+        """dy of node n's output from everything that consumes it.  Returns True when the launch also
+        left the instance-norm backward sums of n in P.red[n.name] (conv nodes: in_bwd_stats is then done)."""
         segs = self._grad_segments(P, n.name)
         samplers = self._sampler_consumers(P, n.name)
         if samplers:
@@ -293,7 +297,12 @@ class Engine(object):
             ops.batch_scatter_add(dps.as_strided((P.B, P.H * P.W, C), (dps.stride(0), dps.stride(2), 1)), P.ps, acc)
             ops.convert(acc.view(P.B, P.Hi, P.W, C), P.dy[n.name][..., :C])
         elif segs:
+            if n.op == "conv":
+                ops.conv_fwd(segs, P.dy[n.name], n.channels,
+                             norm_bwd=(P.a[n.name][..., :n.channels], P.stats[n.name], P.red[n.name]))
+                return True
             ops.conv_fwd(segs, P.dy[n.name], n.channels)
+        return False
 
     # ------------------------------------------------------------------ execution
     def forward(self, grid, image=None, ps_1d_indices=None, labels=None):
@@ -411,11 +420,11 @@ class Engine(object):
         for n in reversed(net.nodes):
             if n.op == "conv":
                 a = n.attrs
-                if n.name != lname:
-                    self._backprop_into(P, n)
+                have_red = self._backprop_into(P, n) if n.name != lname else False
                 dy = P.dy[n.name][..., :n.channels]
                 av = P.a[n.name][..., :n.channels]
-                ops.in_bwd_stats(dy, av, P.stats[n.name], P.red[n.name])
+                if not have_red:
+                    ops.in_bwd_stats(dy, av, P.stats[n.name], P.red[n.name])
                 ops.in_bwd_apply(dy, av, P.stats[n.name], P.red[n.name], P.dz[n.name][..., :n.channels],
                                  dbias_part=P.dbpart[n.name], relu=a.get("activation", "relu"))
                 src = n.inputs[0]

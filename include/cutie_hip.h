@@ -127,6 +127,22 @@ int cutie_conv_fwd(const cutie_conv_seg* segs /* host */, int n_segs,
                    const float* bias, int relu, float* stats, int stats_tiles,
                    int dtype, cutie_stream_t stream);
 
+/* The data gradient of a layer that ends in the instance norm of model_framework.py:423, together with the
+ * first half of that norm's gradient: out = dy as cutie_conv_fwd(flip segments, no bias / activation) gives
+ * it, and red[b][t][c] = (sum dy, sum dy*xhat) exactly as cutie_in_bwd_stats (K6 below) defines it for
+ * (dy = out, a, stats), ready for cutie_in_bwd_apply.  On the wide MFMA kernel the sums are taken in the
+ * store pass of the epilogue from the rounded dy (tile t of a sample STORES slot t; slots the launch does
+ * not own are left alone - zero `red` once when it is allocated); otherwise the conv is followed by
+ * cutie_in_bwd_stats over all red_tiles slots.  red_tiles >= cutie_conv_stats_tiles(H, W).
+ * CUTIE_FUSE_NORM_BWD=0 in the environment selects the two-pass form (A/B measurements). */
+int cutie_conv_dgrad_in_stats(const cutie_conv_seg* segs /* host */, int n_segs,
+                              int B, int H, int W, int n_out,
+                              void* out, int ld_out, int out_dtype,
+                              const void* a, int ld_a, int a_dtype,
+                              const float* stats, int stats_tiles, float eps,
+                              float* red, int red_tiles,
+                              int dtype, cutie_stream_t stream);
+
 /* weight gradient: dw[(i*kw+j)][c][n] (= HWIO, model_framework.py:416) =
  *   sum over b,h,w of x[b, h+(i-kh/2)*dil, w+(j-kw/2)*dil, c] * dz[b,h,w,n].
  * Deterministic: K is split over `splits` row groups into f32 slabs in the workspace, then

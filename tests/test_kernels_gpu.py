@@ -298,6 +298,64 @@ def test_conv_wide_dgrad_multi_segment(ops, dt):
     assert relerr(out, x.grad) < (8e-4 if dt == "f16" else 6e-3)
 
 
+DGRAD_STATS_CASES = [
+    # B, H, W, channels of the consuming conv's output (cin of the data gradient), channels of dy, dil
+    (2, 64, 64, 256, 256, 4),      # wide kernel, channel tile 256: sums taken in the epilogue
+    (1, 42, 63, 64, 256, 1),       # ragged tiles
+    (2, 32, 64, 64, 128, 2),       # channel tile 128 (two workgroups per pixel tile)
+    (1, 40, 64, 128, 64, 16),      # channel tile 64
+    (1, 7, 80, 64, 512, 2),        # two channel tiles of 256, tiles wider than tall
+    (2, 12, 64, 64, 32, 1),        # not a wide-kernel shape: conv + the separate reduction behind the same entry point
+]
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16", "f16"])
+@pytest.mark.parametrize("case", DGRAD_STATS_CASES)
+def test_conv_dgrad_in_stats(ops, dt, case):
+    """cutie_conv_dgrad_in_stats = cutie_conv_fwd (flip) followed by cutie_in_bwd_stats: the same dy bit for bit,
+    the same (sum dy, sum dy*xhat) up to the order of the f32 additions; rerun bit-identical."""
+    B, H, W, cz, C, dil = case
+    g = torch.Generator().manual_seed(hash(case) % 1000 + 3)
+    tdt = TDT[dt]
+    w = (torch.randn((3, 5, C, cz), generator=g) * 0.05).to(tdt).float()     # forward weights C -> cz
+    dz = _rand_act(g, (B, H, W, cz), tdt).to(DEV)
+    a = torch.relu(torch.randn((B, H, W, C), generator=g) + 0.2).to(tdt)
+    ld = C + 8
+    ad = torch.zeros((B, H, W, ld), dtype=tdt, device=DEV)
+    ad[..., :C] = a.to(DEV)
+    T = ops.conv_stats_tiles(H, W)
+    stats = torch.zeros((B, 3, C, 2), dtype=torch.float32, device=DEV)
+    ops.in_stats(ad[..., :C], stats)
+    _, wd = ops.pack_weights(w.to(DEV), CDT[dt], want_fwd=False)
+    seg = [dict(x=dz, w=wd, cin=wd.shape[2], kh=3, kw=5, dil=dil, flip=True)]
+    if wd.shape[2] != cz:
+        pytest.skip("padded cin")
+    dy_ref = torch.full((B, H, W, ld), 2.0, dtype=tdt, device=DEV)
+    ops.conv_fwd(seg, dy_ref[..., :C], C)
+    red_ref = torch.zeros((B, 4, C, 2), dtype=torch.float32, device=DEV)
+    ops.in_bwd_stats(dy_ref[..., :C], ad[..., :C], stats, red_ref)
+    dy = torch.full((B, H, W, ld), 2.0, dtype=tdt, device=DEV)
+    red = torch.zeros((B, T + 2, C, 2), dtype=torch.float32, device=DEV)
+    ops.conv_fwd(seg, dy[..., :C], C, norm_bwd=(ad[..., :C], stats, red))
+    torch.cuda.synchronize()
+    assert torch.equal(dy, dy_ref)
+    # the sums cancel heavily (dy has mean ~0): compare against the magnitude of the summands
+    scale = torch.stack([dy_ref[..., :C].float().abs().sum(dim=(1, 2)), dy_ref[..., :C].float().abs().sum(dim=(1, 2))], dim=-1)
+    err = ((red.sum(dim=1) - red_ref.sum(dim=1)).abs() / (scale + 1e-20)).max()
+    assert float(err) < 1e-5
+    # against float64 of the same rounded operands
+    a64, d64 = ad[..., :C].double().cpu(), dy_ref[..., :C].double().cpu()
+    mean = a64.mean(dim=(1, 2), keepdim=True)
+    var = (a64 ** 2).mean(dim=(1, 2), keepdim=True) - mean ** 2
+    xh = (a64 - mean) / torch.sqrt(var.clamp_min(0) + 1e-6)
+    ref64 = torch.stack([d64.sum(dim=(1, 2)), (d64 * xh).sum(dim=(1, 2))], dim=-1)
+    err64 = ((red.sum(dim=1).double().cpu() - ref64).abs() / (scale.double().cpu() * 2 + 1e-20)).max()
+    assert float(err64) < 1e-4
+    dy2, red2 = torch.full_like(dy, 2.0), torch.zeros_like(red)
+    ops.conv_fwd(seg, dy2[..., :C], C, norm_bwd=(ad[..., :C], stats, red2))
+    assert torch.equal(dy, dy2) and torch.equal(red, red2)
+
+
 @pytest.mark.parametrize("dt", ["f32", "bf16", "f16"])
 def test_conv_dgrad_multi_segment(ops, dt):
     """d(loss)/dx of a tensor consumed by two convs (3x5 dil 2 with 128 outputs, and channels
