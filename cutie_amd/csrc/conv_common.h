@@ -16,6 +16,8 @@ struct Seg {
     int ld_x, cin, kh, kw, dil, sgn;
 };
 
+constexpr int CONV_MAX_PERM = 128;
+
 struct ConvParams {
     Seg seg[CUTIE_MAX_SEGS];
     int nseg;
@@ -38,6 +40,10 @@ struct ConvParams {
     float bw_eps;
     float* bw_red;           // [B][bw_red_tiles][n_out][2]
     int bw_red_tiles;
+    // conv_wide: order in which an XCD takes the pixel tiles of its samples - heaviest (most live taps)
+    // first, so that the light corner tiles of a dilated layer fill the end of the launch.  0 = row-major.
+    int perm_n;
+    unsigned char perm[CONV_MAX_PERM];
 };
 
 template <int DT> struct Traits;

@@ -769,7 +769,7 @@ static int conv_fwd_impl(const cutie_conv_seg* segs, int n_segs, int B, int H, i
 
     ConvParams p;
     p.nseg = n_segs;
-    p.bw_a = nullptr; p.bw_ld_a = 0; p.bw_stats = nullptr; p.bw_stats_tiles = 0; p.bw_eps = 0.f; p.bw_red = nullptr; p.bw_red_tiles = 0;
+    p.bw_a = nullptr; p.bw_ld_a = 0; p.bw_stats = nullptr; p.bw_stats_tiles = 0; p.bw_eps = 0.f; p.bw_red = nullptr; p.bw_red_tiles = 0; p.perm_n = 0;
     int twb, th_g;
     generic_tiling(W, th_g, twb);
     p.TWB = twb;

@@ -215,11 +215,24 @@ __global__ __launch_bounds__(CW_NT) void conv_wide_kernel(ConvParams p) {
     // tiles so that neighbouring tiles (shared halos) meet in one L2
     int bid = blockIdx.x;
     const int nwg = gridDim.x;
-    if ((nwg & 7) == 0) bid = (bid & 7) * (nwg >> 3) + (bid >> 3);
-    const int nt = bid % p.n_tiles_n; bid /= p.n_tiles_n;
-    const int tw = bid % p.tiles_w; bid /= p.tiles_w;
-    const int th = bid % p.tiles_h;
-    const int b = bid / p.tiles_h;
+    int nt, tw, th, b;
+    if (p.perm_n) {
+        // B % 8 == 0 (checked on the host): XCD x owns samples [x*S, (x+1)*S) and takes their tiles position by
+        // position in the order of p.perm - all samples' heaviest tile first
+        const int S = p.B >> 3;
+        int l = bid >> 3;
+        nt = l % p.n_tiles_n; l /= p.n_tiles_n;
+        b = (bid & 7) * S + l % S;
+        const int tile = p.perm[l / S];
+        th = tile / p.tiles_w;
+        tw = tile - th * p.tiles_w;
+    } else {
+        if ((nwg & 7) == 0) bid = (bid & 7) * (nwg >> 3) + (bid >> 3);
+        nt = bid % p.n_tiles_n; bid /= p.n_tiles_n;
+        tw = bid % p.tiles_w; bid /= p.tiles_w;
+        th = bid % p.tiles_h;
+        b = bid / p.tiles_h;
+    }
     const int h0 = th * TR, w0 = tw * TC, n0 = nt * BN;
 
     float4_t acc[MB][4];
@@ -406,12 +419,57 @@ static int launch_one(const ConvParams& p, hipStream_t stream) {
     return CUTIE_OK;
 }
 
+// Heaviest-first tile order (ConvParams::perm): the K steps of a tile are its live taps x channel chunks, which on
+// a dilated layer differ up to 2x between the centre and the corners of the image.  Dispatch is in block order, so
+// putting the heavy tiles first lets the light ones even out the end of the launch.
+static void plan_tile_order(ConvParams& p) {
+    static const bool on = !(getenv("CUTIE_CONV_LPT") && atoi(getenv("CUTIE_CONV_LPT")) == 0);
+    p.perm_n = 0;
+    const int nt = p.tiles_h * p.tiles_w;
+    if (!on || nt < 2 || nt > CONV_MAX_PERM || (p.B & 7) != 0) return;
+    const int TR = p.TH, TC = p.TWB * 16;
+    int weight[CONV_MAX_PERM];
+    int wmin = 1 << 30, wmax = 0;
+    for (int t = 0; t < nt; ++t) {
+        const int h0 = (t / p.tiles_w) * TR, w0 = (t % p.tiles_w) * TC;
+        int w = 0;
+        for (int s = 0; s < p.nseg; ++s) {
+            const Seg& g = p.seg[s];
+            int live = 0;
+            for (int i = 0; i < g.kh; ++i) {
+                const int sy = g.sgn * (i - g.kh / 2) * g.dil;
+                if (h0 + sy + TR - 1 < 0 || h0 + sy >= p.H) continue;
+                for (int j = 0; j < g.kw; ++j) {
+                    const int sx = g.sgn * (j - g.kw / 2) * g.dil;
+                    if (w0 + sx + TC - 1 < 0 || w0 + sx >= p.W) continue;
+                    ++live;
+                }
+            }
+            w += live * (g.cin >> 6);
+        }
+        weight[t] = w;
+        if (w < wmin) wmin = w;
+        if (w > wmax) wmax = w;
+    }
+    if (wmin == wmax) return;
+    for (int t = 0; t < nt; ++t) p.perm[t] = (unsigned char)t;
+    for (int i = 1; i < nt; ++i) {          // stable insertion sort, heaviest first
+        const unsigned char v = p.perm[i];
+        int j = i - 1;
+        while (j >= 0 && weight[p.perm[j]] < weight[v]) { p.perm[j + 1] = p.perm[j]; --j; }
+        p.perm[j + 1] = v;
+    }
+    p.perm_n = nt;
+}
+
 // p.TH / p.TWB / tiles_* must describe 256-pixel tiles, p.n_tiles_n = n_out / bn
-int launch_conv_wide(const ConvParams& p, int dtype, int bn, hipStream_t stream) {
+int launch_conv_wide(const ConvParams& p0, int dtype, int bn, hipStream_t stream) {
     if (dtype != CUTIE_BF16 && dtype != CUTIE_F16) {
         set_error("conv_wide: dtype %d", dtype);
         return CUTIE_E_ARG;
     }
+    ConvParams p = p0;
+    plan_tile_order(p);
     const bool bf = dtype == CUTIE_BF16;
     switch (bn) {
         case 256: return bf ? launch_one<CUTIE_BF16, 256>(p, stream) : launch_one<CUTIE_F16, 256>(p, stream);

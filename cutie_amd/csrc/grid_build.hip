@@ -67,7 +67,17 @@ __global__ __launch_bounds__(GB_NT) void grid_build_kernel(GridArgs a) {
     int32_t* key_id = in_lds ? key_col + a.cap : const_cast<int32_t*>(a.tok_id) + t0;
     int32_t* order = in_lds ? key_id + a.cap : a.tok_order + t0;
 
-    for (int i = tid; i < rows * cols; i += GB_NT) g[i] = 0;
+    // the document's output cells start at zero (the barrier below orders these stores before the
+    // placement lanes' stores to the same cells)
+    {
+        const size_t c0 = (size_t)doc * rows * cols;
+        for (int i = tid; i < rows * cols; i += GB_NT) {
+            g[i] = 0;
+            a.labels[c0 + i] = 0;
+            a.ps_x[c0 + i] = 0;
+            a.ps_y[c0 + i] = 0;
+        }
+    }
     for (int i = tid; i < rows; i += GB_NT) row_start[i] = -1;
     if (tid == 0) *flag = 0;
     __syncthreads();
@@ -104,6 +114,11 @@ __global__ __launch_bounds__(GB_NT) void grid_build_kernel(GridArgs a) {
     if (*flag) {
         if (tid == 0) a.status[doc] = 1;
         for (int i = tid; i < rows * cols; i += GB_NT) a.grid[(size_t)doc * rows * cols + i] = 0;
+        for (int i = tid; i < n; i += GB_NT) {      // a rejected document places nothing
+            a.tok_order[t0 + i] = -1;
+            a.tok_place[(t0 + i) * 2 + 0] = -1;
+            a.tok_place[(t0 + i) * 2 + 1] = -1;
+        }
         return;
     }
 
@@ -214,11 +229,6 @@ extern "C" int cutie_grid_build(const int32_t* tok_box, const int32_t* tok_id, c
                          cutie_grid_build_workspace_bytes(n_tokens));
         return CUTIE_E_WORKSPACE;
     }
-    const size_t cells = (size_t)n_docs * rows * cols;
-    CUTIE_CHECK_HIP(hipMemsetAsync(labels, 0, cells, stream));
-    CUTIE_CHECK_HIP(hipMemsetAsync(ps_x, 0, cells * 4, stream));
-    CUTIE_CHECK_HIP(hipMemsetAsync(ps_y, 0, cells * 4, stream));
-
     GridArgs a;
     a.tok_box = tok_box; a.tok_id = tok_id; a.tok_ecid = tok_ecid;
     a.doc_extent = doc_extent; a.doc_off = doc_off;

@@ -160,16 +160,17 @@ template <int VEC, typename TA, typename TY>
 __global__ __launch_bounds__(256) void in_apply_kernel(const TA* __restrict__ a, int ld_a,
                                                        const float* __restrict__ stats, int st, float eps,
                                                        TY* __restrict__ y, int ld_y, int HW, int C) {
-    __shared__ float tab[2][256 * VEC];
+    extern __shared__ float tab[];      // [2][C]
     const int CV = C / VEC;
     const Map m = make_map(HW, CV);
     const float inv_n = 1.f / (float)HW;
-    fold_slots<1>(stats, m.b, st, C, inv_n, eps, tab[0], tab[1]);
+    fold_slots<1>(stats, m.b, st, C, inv_n, eps, tab, tab + C);
     __syncthreads();
     if (!m.active) return;
     float mean[VEC], inv[VEC];
 #pragma unroll
-    for (int e = 0; e < VEC; ++e) { mean[e] = tab[0][m.cl * VEC + e]; inv[e] = tab[1][m.cl * VEC + e]; }
+    for (int e = 0; e < VEC; ++e) { mean[e] = tab[m.cl * VEC + e]; inv[e] = tab[C + m.cl * VEC + e]; }
+#pragma unroll 4
     for (int hw = m.hw0 + m.sub; hw < m.hw1; hw += m.rows_par) {
         const int64_t row = (int64_t)m.b * HW + hw;
         vecf<VEC> x = loadv<VEC>(a + row * ld_a + m.cl * VEC);
@@ -185,16 +186,16 @@ __global__ __launch_bounds__(256) void in_bwd_stats_kernel(const TD* __restrict_
                                                            const float* __restrict__ stats, int st, float eps,
                                                            float* __restrict__ redout, int HW, int C) {
     __shared__ float red[2][256][VEC];
-    __shared__ float tab[2][256 * VEC];
+    extern __shared__ float tab[];      // [2][C]
     const int CV = C / VEC;
     const Map m = make_map(HW, CV);
-    fold_slots<1>(stats, m.b, st, C, 1.f / (float)HW, eps, tab[0], tab[1]);
+    fold_slots<1>(stats, m.b, st, C, 1.f / (float)HW, eps, tab, tab + C);
     __syncthreads();
     float s1[VEC] = {}, s2[VEC] = {};
     if (m.active) {
         float mean[VEC], inv[VEC];
 #pragma unroll
-        for (int e = 0; e < VEC; ++e) { mean[e] = tab[0][m.cl * VEC + e]; inv[e] = tab[1][m.cl * VEC + e]; }
+        for (int e = 0; e < VEC; ++e) { mean[e] = tab[m.cl * VEC + e]; inv[e] = tab[C + m.cl * VEC + e]; }
 #pragma unroll 4
         for (int hw = m.hw0 + m.sub; hw < m.hw1; hw += m.rows_par) {
             const int64_t row = (int64_t)m.b * HW + hw;
@@ -221,12 +222,12 @@ __global__ __launch_bounds__(256) void in_bwd_apply_kernel(const TD* __restrict_
                                                            TZ* __restrict__ dz, int ld_dz,
                                                            float* __restrict__ dbias, int HW, int C) {
     __shared__ float red[1][256][VEC];
-    __shared__ float tab[4][256 * VEC];
+    extern __shared__ float tab[];      // [4][C]
     const int CV = C / VEC;
     const Map m = make_map(HW, CV);
     const float inv_n = 1.f / (float)HW;
-    fold_slots<1>(stats, m.b, st, C, inv_n, eps, tab[0], tab[1]);
-    fold_slots<0>(redin, m.b, rt, C, inv_n, eps, tab[2], tab[3]);
+    fold_slots<1>(stats, m.b, st, C, inv_n, eps, tab, tab + C);
+    fold_slots<0>(redin, m.b, rt, C, inv_n, eps, tab + 2 * C, tab + 3 * C);
     __syncthreads();
     float sb[VEC] = {};
     if (m.active) {
@@ -234,11 +235,12 @@ __global__ __launch_bounds__(256) void in_bwd_apply_kernel(const TD* __restrict_
 #pragma unroll
         for (int e = 0; e < VEC; ++e) {
             const int c = m.cl * VEC + e;
-            mean[e] = tab[0][c];
-            inv[e] = tab[1][c];
-            m1[e] = tab[2][c] * inv_n;
-            m2[e] = tab[3][c] * inv_n;
+            mean[e] = tab[c];
+            inv[e] = tab[C + c];
+            m1[e] = tab[2 * C + c] * inv_n;
+            m2[e] = tab[3 * C + c] * inv_n;
         }
+#pragma unroll 4
         for (int hw = m.hw0 + m.sub; hw < m.hw1; hw += m.rows_par) {
             const int64_t row = (int64_t)m.b * HW + hw;
             const vecf<VEC> g = loadv<VEC>(dy + row * ld_dy + m.cl * VEC);
@@ -311,18 +313,18 @@ __global__ __launch_bounds__(256) void mean_bcast_kernel(const TX* __restrict__ 
 template <int VEC, typename TO>
 __global__ __launch_bounds__(256) void bcast_mean_kernel(const float* __restrict__ sums, int st, TO* __restrict__ out,
                                                          int ld_out, int HW, int C, int rows_per_wg) {
-    __shared__ float tab[2][256 * VEC];
+    extern __shared__ float tab[];      // [2][C]
     const int CV = C / VEC;
     const int b = blockIdx.y;
     const int rows_par = 256 / CV;
     const int cl = threadIdx.x % CV, sub = threadIdx.x / CV;
-    fold_slots<0>(sums, b, st, C, 0.f, 0.f, tab[0], tab[1]);
+    fold_slots<0>(sums, b, st, C, 0.f, 0.f, tab, tab + C);
     __syncthreads();
     if (sub >= rows_par) return;
     vecf<VEC> mv;
     const float inv = 1.f / (float)HW;
 #pragma unroll
-    for (int e = 0; e < VEC; ++e) mv.v[e] = tab[0][cl * VEC + e] * inv;
+    for (int e = 0; e < VEC; ++e) mv.v[e] = tab[cl * VEC + e] * inv;
     const int r0 = blockIdx.x * rows_per_wg;
     const int r1 = min(HW, r0 + rows_per_wg);
     for (int hw = r0 + sub; hw < r1; hw += rows_par) storev<VEC>(out + ((int64_t)b * HW + hw) * ld_out + cl * VEC, mv);
@@ -396,7 +398,7 @@ extern "C" int cutie_in_apply(const void* a, int ld_a, int a_dtype, const float*
     const dim3 g = reduce_grid(B, HW, C, vec);
     CUTIE_DISPATCH_DTYPE(a_dtype, ADT, CUTIE_DISPATCH_DTYPE(y_dtype, YDT, NORM_DISPATCH_VEC(vec,
         hipLaunchKernelGGL((in_apply_kernel<VEC, typename elem<ADT>::type, typename elem<YDT>::type>), g, dim3(256),
-                           0, stream, (const typename elem<ADT>::type*)a, ld_a, stats, stats_tiles, eps,
+                           2 * C * sizeof(float), stream, (const typename elem<ADT>::type*)a, ld_a, stats, stats_tiles, eps,
                            (typename elem<YDT>::type*)y, ld_y, HW, C))));
     CUTIE_CHECK_LAUNCH();
     return CUTIE_OK;
@@ -414,7 +416,7 @@ extern "C" int cutie_in_bwd_stats(const void* dy, int ld_dy, int dy_dtype, const
     const dim3 g(red_tiles, B);
     CUTIE_DISPATCH_DTYPE(dy_dtype, DDT, CUTIE_DISPATCH_DTYPE(a_dtype, ADT, NORM_DISPATCH_VEC(vec,
         hipLaunchKernelGGL((in_bwd_stats_kernel<VEC, typename elem<DDT>::type, typename elem<ADT>::type>), g,
-                           dim3(256), 0, stream, (const typename elem<DDT>::type*)dy, ld_dy,
+                           dim3(256), 2 * C * sizeof(float), stream, (const typename elem<DDT>::type*)dy, ld_dy,
                            (const typename elem<ADT>::type*)a, ld_a, stats, stats_tiles, eps, red, HW, C))));
     CUTIE_CHECK_LAUNCH();
     return CUTIE_OK;
@@ -436,7 +438,7 @@ extern "C" int cutie_in_bwd_apply(const void* dy, int ld_dy, int dy_dtype, const
     const dim3 g = dbias ? dim3(dbias_tiles, B) : reduce_grid(B, HW, C, vec);
     CUTIE_DISPATCH_DTYPE(dy_dtype, DDT, CUTIE_DISPATCH_DTYPE(a_dtype, ADT, NORM_DISPATCH_VEC(vec,
         hipLaunchKernelGGL((in_bwd_apply_kernel<VEC, typename elem<DDT>::type, typename elem<ADT>::type,
-                                                typename elem<ADT>::type>), g, dim3(256), 0, stream,
+                                                typename elem<ADT>::type>), g, dim3(256), 4 * C * sizeof(float), stream,
                            (const typename elem<DDT>::type*)dy, ld_dy, (const typename elem<ADT>::type*)a, ld_a,
                            stats, stats_tiles, eps, red, red_tiles, relu, (typename elem<ADT>::type*)dz, ld_dz, dbias,
                            HW, C))));
@@ -513,7 +515,7 @@ extern "C" int cutie_spatial_mean_bcast(const void* x, int ld_x, int x_dtype, vo
         int rows_per_wg = rows_par * 8;
         const dim3 g((HW + rows_per_wg - 1) / rows_per_wg, B);
         CUTIE_DISPATCH_DTYPE(out_dtype, ODT, NORM_DISPATCH_VEC(vec,
-            hipLaunchKernelGGL((bcast_mean_kernel<VEC, typename elem<ODT>::type>), g, dim3(256), 0, stream,
+            hipLaunchKernelGGL((bcast_mean_kernel<VEC, typename elem<ODT>::type>), g, dim3(256), 2 * C * sizeof(float), stream,
                                (const float*)scratch, st, (typename elem<ODT>::type*)out, ld_out, HW, C, rows_per_wg)));
         CUTIE_CHECK_LAUNCH();
         return CUTIE_OK;

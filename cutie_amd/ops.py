@@ -31,9 +31,10 @@ def grid_build(tok_box, tok_id, tok_ecid, doc_extent, doc_off, rows, cols, strat
     labels = torch.empty((B, rows, cols), dtype=torch.int8, device=dev)
     ps_x = torch.empty((B, rows, cols), dtype=torch.int32, device=dev)
     ps_y = torch.empty((B, rows, cols), dtype=torch.int32, device=dev)
-    order = torch.full((max(T, 1),), -1, dtype=torch.int32, device=dev)
-    place = torch.full((max(T, 1), 2), -1, dtype=torch.int32, device=dev)
-    status = torch.zeros((max(B, 1),), dtype=torch.int32, device=dev)
+    # the kernel writes every entry of these three (-1 for the tokens of a rejected document)
+    order = torch.empty((max(T, 1),), dtype=torch.int32, device=dev)
+    place = torch.empty((max(T, 1), 2), dtype=torch.int32, device=dev)
+    status = torch.empty((max(B, 1),), dtype=torch.int32, device=dev)
     ws_bytes = capi.lib().cutie_grid_build_workspace_bytes(T)
     ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev)
     call("cutie_grid_build", ptr(tok_box), ptr(tok_id), ptr(tok_ecid), ptr(doc_extent), ptr(doc_off), B, T,

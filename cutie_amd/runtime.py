@@ -195,8 +195,8 @@ class Engine(object):
         pooled = [n.inputs[0].channels for n in nodes if n.op == "global_pool"]
         P.pool_scratch = (torch.zeros(B * capi.POOL_TILES * max(pooled) * 2, dtype=torch.float32, device=dev)
                           if pooled else None)
-        P.oob = torch.zeros(1, dtype=torch.int32, device=dev)
-        P.bad = torch.zeros(1, dtype=torch.int32, device=dev)
+        P.counters = torch.zeros(2, dtype=torch.int32, device=dev)     # one fill per forward clears both
+        P.oob, P.bad = P.counters[0:1], P.counters[1:2]
         N = B * H * W
         P.N = N
         P.ce = torch.zeros(N, dtype=torch.float32, device=dev)
@@ -326,8 +326,8 @@ class Engine(object):
         if Hi:
             P.bufs["data_image"][..., :3].copy_(img.to(self.dev))
             P.ps.copy_(torch.as_tensor(ps_1d_indices).to(torch.int32).reshape(B, H * W))
-        P.stats_all.zero_()
-        P.oob.zero_()
+        # P.stats_all needs no clearing: every launch stores the same slots of it again, the others stay zero
+        P.counters.zero_()
         for n in net.nodes:
             if n.op == "embed":
                 ops.embed_fwd(P.grid, self.params[n.name + "/weights"], P.view(n.name, n.channels), P.oob)
@@ -357,7 +357,6 @@ class Engine(object):
                                      (P.view(n.name, n.channels).stride(0), P.view(n.name, n.channels).stride(2), 1)))
             elif n.op == "softmax":
                 src = n.inputs[0]
-                P.bad.zero_()
                 lab = P.labels if labels is not None else P.zero_labels
                 ops.softmax_ce_fwd(P.view(src.name, src.channels), lab, src.channels, P.ce, P.probs, P.bad)
             else:
@@ -414,7 +413,9 @@ class Engine(object):
         else:
             ops.hnm_weights(P.ce, P.labels, int(spec["hard_negative_ratio"]), P.weight, P.loss, P.hnm_ws)
             ops.softmax_ce_bwd(P.probs, P.labels, P.weight, C, P.dy[lname][..., :C], ls)
-        self.grads_flat.zero_()
+        # conv kernels and biases are overwritten by their gradient kernels (the padding between tensors is
+        # never written and stays zero); only the embedding gradient is accumulated into
+        self.grads_flat[self.n_dense:].zero_()
         P.reg.zero_()
         wd = float(spec["weight_decay"])
         for n in reversed(net.nodes):

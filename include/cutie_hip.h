@@ -61,8 +61,9 @@ const char* cutie_last_error(void);
  *            tok_place int32 [T,2]: (row,col) where that k-th token was written, (-1,-1) if
  *                 strategy 0 dropped it
  *            status int32 [B]: 0 ok; 1 = some token maps outside the grid (the reference
- *                 raises IndexError or writes into its cropped buffer half); outputs of such
- *                 a document are unspecified.
+ *                 raises IndexError or writes into its cropped buffer half); such a document
+ *                 gets an all-zero grid / labels / ps and -1 in its tok_order / tok_place.
+ *            Every element of every output is written by the call (nothing to pre-fill).
  * workspace  cutie_grid_build_workspace_bytes(T) bytes.
  * limits     rows*cols*4 bytes must fit the 160 KB LDS (<= 36864 cells), rows <= 1024.
  */

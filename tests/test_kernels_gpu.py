@@ -237,6 +237,10 @@ WIDE_CASES = [
     (1, 33, 50, 64, 384, 3, 5, 4),
     (2, 20, 64, 128, 192, 1, 1, 1),
     (1, 40, 64, 64, 64, 3, 5, 16),
+    # B % 8 == 0 with unequal live taps per tile: the heaviest-first tile order
+    (8, 64, 64, 64, 256, 3, 5, 16),
+    (8, 32, 64, 64, 128, 3, 5, 8),
+    (16, 20, 40, 64, 64, 3, 3, 4),
 ]
 
 
@@ -306,6 +310,7 @@ DGRAD_STATS_CASES = [
     (1, 40, 64, 128, 64, 16),      # channel tile 64
     (1, 7, 80, 64, 512, 2),        # two channel tiles of 256, tiles wider than tall
     (2, 12, 64, 64, 32, 1),        # not a wide-kernel shape: conv + the separate reduction behind the same entry point
+    (8, 64, 64, 64, 256, 16),      # heaviest-first tile order: slots are still indexed by the tile, not by the block
 ]
 
 
