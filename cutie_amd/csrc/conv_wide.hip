@@ -331,9 +331,15 @@ __global__ __launch_bounds__(CW_NT) void conv_wide_kernel(ConvParams p) {
             // barriers keep hipcc from gathering the loads into one burst
 #pragma unroll
             for (int m = 0; m < MB; ++m) {
+#ifndef CW_ISSUE_MODE
+#define CW_ISSUE_MODE 1      // A/B on the MI355X (tools/gpu_variants.sh): mode 1 is 0.5 % of a step ahead of 0 and 2
+#endif
 #pragma unroll
-                for (int q = 0; q < NP; ++q)
-                    if ((q * MB) / NP == m) prefetch(q);
+                for (int q = 0; q < NP; ++q) {
+                    if (CW_ISSUE_MODE == 0 && (q * MB) / NP == m) prefetch(q);            // spread over the first K half
+                    if (CW_ISSUE_MODE == 1 && (q * MB) / (2 * NP) == m) prefetch(q);      // first quarter, two per group
+                    if (CW_ISSUE_MODE == 2 && m == 0) prefetch(q);                        // burst before the first MFMA
+                }
                 if (m == MB / 2 - 1) {
 #pragma unroll
                     for (int n = 0; n < 4; ++n) bf1[n] = *reinterpret_cast<const uint4*>(Bt + b_rd[1] + n * 2048);
