@@ -274,7 +274,7 @@ __global__ __launch_bounds__(256) void in_bwd_apply_kernel(const TD* __restrict_
                 o.v[e] = d;
                 sb[e] += d;
             }
-            storev<VEC, true>(dz + row * ld_dz + m.cl * VEC, o);
+            storev<VEC>(dz + row * ld_dz + m.cl * VEC, o);     // plain store: dz is read again at once by dgrad and wgrad
         }
     }
     if (dbias) {   // one row of partials per (sample, H*W slice): [B * gridDim.x][C], folded by sum_rows
