@@ -18,6 +18,7 @@ A tensor with several consumers gets its gradient from ONE multi-segment data-gr
 launch over all consuming convs (also through concats, by weight-row offset).
 """
 import math
+import os
 from collections import OrderedDict
 
 import numpy as np
@@ -36,7 +37,7 @@ class _Plan(object):
 
 
 class Engine(object):
-    def __init__(self, network, device="cuda:0", dtype="bf16", seed=0, loss_scale=None):
+    def __init__(self, network, device="cuda:0", dtype="bf16", seed=0, loss_scale=None, overlap_wgrad=None):
         """dtype: 'bf16' (the headline path), 'f16' (same MFMA rate, 8x finer rounding; backward runs
         under a dynamic loss scale kept on the device, initial value `loss_scale`, default 4096) or
         'f32' (parity mode)."""
@@ -52,6 +53,16 @@ class Engine(object):
             loss_scale = 4096.0
         with torch.cuda.device(self.dev):
             self.loss_scale = ops.loss_scale_state(loss_scale, self.dev) if loss_scale else None
+        # Optional: backward on two HIP streams - the weight gradients (MFMA-bound, needed only by the optimizer
+        # and the all-reduce) beside the data-gradient / norm-backward chain (whose norm passes are HBM-bound).
+        # Off by default: measured on the MI355X (tools/gpu_overlap.sh, alternating runs on one box) it is 0.45 %
+        # SLOWER than one stream (3914 / 3916 vs 3932 / 3933 docs/s) - conv_wide and wgrad5 each fill a CU's LDS,
+        # so the two matrix kernels only take turns, and the norm passes gain nothing beside them.
+        # CUTIE_OVERLAP_WGRAD=1 or overlap_wgrad=True turns it on.
+        if overlap_wgrad is None:
+            overlap_wgrad = os.environ.get("CUTIE_OVERLAP_WGRAD", "0") == "1"
+        self.overlap_wgrad = bool(overlap_wgrad)
+        self._side = None
         self.C = network.num_classes
         self._plans = {}
         self._layout_params()
@@ -418,6 +429,12 @@ class Engine(object):
         self.grads_flat[self.n_dense:].zero_()
         P.reg.zero_()
         wd = float(spec["weight_decay"])
+        main = torch.cuda.current_stream(self.dev)
+        side = None
+        if self.overlap_wgrad:
+            if self._side is None:
+                self._side = torch.cuda.Stream(device=self.dev)
+            side = self._side
         for n in reversed(net.nodes):
             if n.op == "conv":
                 a = n.attrs
@@ -429,18 +446,27 @@ class Engine(object):
                 ops.in_bwd_apply(dy, av, P.stats[n.name], P.red[n.name], P.dz[n.name][..., :n.channels],
                                  dbias_part=P.dbpart[n.name], relu=a.get("activation", "relu"))
                 src = n.inputs[0]
-                ops.conv_wgrad(P.view(src.name, a["cin"]), a["cin"], P.dz[n.name][..., :n.channels], n.channels,
-                               a["kh"], a["kw"], a["rate"], self.grads[n.name + "/weights"], P.wgrad_ws)
-                if on_ready is not None:
-                    off, cnt, _ = self.offsets[n.name + "/weights"]
-                    ops.l2_add(self.params_flat[off:off + cnt], self.grads_flat[off:off + cnt], wd, P.reg, P.scratch, ls)
-                    on_ready(_pad(off + cnt, 64))
+                if side is not None:
+                    # dz of this layer is final: its weight gradient (and, data-parallel, the L2 term and the
+                    # bucket hand-off) goes to the side stream, in layer order, sharing one workspace
+                    ev = torch.cuda.Event()
+                    ev.record(main)
+                    side.wait_event(ev)
+                with torch.cuda.stream(side if side is not None else main):
+                    ops.conv_wgrad(P.view(src.name, a["cin"]), a["cin"], P.dz[n.name][..., :n.channels], n.channels,
+                                   a["kh"], a["kw"], a["rate"], self.grads[n.name + "/weights"], P.wgrad_ws)
+                    if on_ready is not None:
+                        off, cnt, _ = self.offsets[n.name + "/weights"]
+                        ops.l2_add(self.params_flat[off:off + cnt], self.grads_flat[off:off + cnt], wd, P.reg, P.scratch, ls)
+                        on_ready(_pad(off + cnt, 64))
             elif n.op == "positional_sampling":
                 self._backprop_into(P, n)
             elif n.op == "embed":
                 self._backprop_into(P, n)
                 ops.embed_bwd(P.grid, P.dy[n.name][..., :n.channels], self.grads[n.name + "/weights"])
                 P.d_embed = P.dy[n.name]
+        if side is not None:
+            main.wait_stream(side)     # every weight gradient is in place; the buffers it read may be reused
         # bias gradients: fold the per-sample partials of every layer in one launch
         if getattr(P, "_sum_rows_batches", None) is None:
             # partial rows per layer differ (B x slices of H*W): group the layers by row count
