@@ -51,7 +51,8 @@ SIGNATURES = {
     "cutie_grid_build": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                               _vp, _sz, _vp]),
     "cutie_embed_fwd": (_i, [_vp, _i64, _vp, _i, _i, _vp, _i, _i, _vp, _vp]),
-    "cutie_embed_bwd": (_i, [_vp, _i64, _vp, _i, _i, _vp, _i, _i, _vp]),
+    "cutie_embed_bwd_workspace_bytes": (_sz, [_i64, _i]),
+    "cutie_embed_bwd": (_i, [_vp, _i64, _vp, _i, _i, _vp, _i, _i, _vp, _sz, _vp]),
     "cutie_conv_stats_tiles": (_i, [_i, _i]),
     "cutie_conv_fwd": (_i, [_c.POINTER(ConvSeg), _i, _i, _i, _i, _i, _vp, _i, _i, _vp, _i, _vp, _i, _i, _vp]),
     "cutie_conv_dgrad_in_stats": (_i, [_c.POINTER(ConvSeg), _i, _i, _i, _i, _i, _vp, _i, _i, _vp, _i, _i, _vp, _i, _f, _vp,

@@ -2,6 +2,7 @@
 // All HBM-bound row copies: one lane moves 4 consecutive elements, a row is read by
 // consecutive lanes (model_framework.py:43-54, :73-86).
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 using namespace cutie;
@@ -27,13 +28,30 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(const int32_t* __restric
     }
 }
 
-// dtable[id] += dout[cell]; ids 0/1 are summed in registers, then LDS, then one atomic per WG
+// dtable[id] += dout[cell] (tf.nn.embedding_lookup's gradient, model_framework.py:51).
+// What bounds a scatter-add into an embedding table is same-address float atomics (measured, tools/embed_bench.py:
+// 8226 cells onto ONE row take 790 us, onto distinct rows 5 us), and a document grid is exactly that input: most
+// cells hold id 0, a third of the tokens id 1 ([UNK]) and the rest follow a Zipf law.  So:
+//   * ids 0 and 1 are summed in registers, then over the workgroup in LDS, and the workgroup's two partial rows are
+//     STORED into `partials` [G][2][E] (folded in workgroup order by embed_bwd_fold_kernel: no atomics, same bits
+//     every run).  Without a workspace they go out as one atomic per workgroup and element;
+//   * every other id is first summed per workgroup in an LDS table of `slots` rows (open addressing on the id), so
+//     that a frequent id costs one global atomic per workgroup and element instead of one per cell; a cell that
+//     finds the table full adds straight into the global row.
+// Bench batch (131072 cells, 8226 of them with an id >= 2): 96 -> 36 us; all of those cells on ONE id: 790 -> 42 us.
 template <int DT>
 __global__ __launch_bounds__(256) void embed_bwd_kernel(const int32_t* __restrict__ ids, int64_t n_cells,
                                                         const typename elem<DT>::type* __restrict__ dout,
                                                         int ld, float* __restrict__ dtable, int V, int E4,
-                                                        int cells_per_wg) {
+                                                        int cells_per_wg, float* __restrict__ partials, int slots) {
     __shared__ float4 red[2][256];
+    extern __shared__ __attribute__((aligned(16))) char dyn[];
+    int* keys = reinterpret_cast<int*>(dyn);                               // [slots]
+    float* rows = reinterpret_cast<float*>(dyn + ((slots * 4 + 15) & ~15)); // [slots][E]
+    const int E = E4 * 4;
+    for (int i = threadIdx.x; i < slots; i += 256) keys[i] = -1;
+    for (int i = threadIdx.x; i < slots * E; i += 256) rows[i] = 0.f;
+    __syncthreads();
     const int rows_par = 256 / E4;        // rows handled side by side
     const int q = threadIdx.x % E4;
     const int sub = threadIdx.x / E4;
@@ -65,7 +83,17 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(const int32_t* __restric
                 } else if (id[u] == 1) {
                     acc1.x += g[u].x; acc1.y += g[u].y; acc1.z += g[u].z; acc1.w += g[u].w;
                 } else {
-                    float* dst = dtable + (int64_t)id[u] * E4 * 4 + q * 4;
+                    // every lane of the cell walks the same probe sequence, so all of them end on the same slot
+                    int slot = -1;
+                    if (slots > 0) {
+                        unsigned h = ((unsigned)id[u] * 2654435761u) >> 8;
+                        for (int pr = 0; pr < 8; ++pr) {
+                            const int sidx = (int)((h + (unsigned)pr) % (unsigned)slots);
+                            const int old = atomicCAS(&keys[sidx], -1, id[u]);
+                            if (old == -1 || old == id[u]) { slot = sidx; break; }
+                        }
+                    }
+                    float* dst = slot >= 0 ? rows + slot * E + q * 4 : dtable + (int64_t)id[u] * E + q * 4;
                     atomicAdd(dst + 0, g[u].x); atomicAdd(dst + 1, g[u].y);
                     atomicAdd(dst + 2, g[u].z); atomicAdd(dst + 3, g[u].w);
                 }
@@ -82,12 +110,45 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(const int32_t* __restric
             s0.x += a.x; s0.y += a.y; s0.z += a.z; s0.w += a.w;
             s1.x += b.x; s1.y += b.y; s1.z += b.z; s1.w += b.w;
         }
-        float* d0 = dtable + q * 4;
-        atomicAdd(d0 + 0, s0.x); atomicAdd(d0 + 1, s0.y); atomicAdd(d0 + 2, s0.z); atomicAdd(d0 + 3, s0.w);
-        if (V > 1) {
-            float* d1 = dtable + (int64_t)E4 * 4 + q * 4;
-            atomicAdd(d1 + 0, s1.x); atomicAdd(d1 + 1, s1.y); atomicAdd(d1 + 2, s1.z); atomicAdd(d1 + 3, s1.w);
+        if (partials) {
+            float* p0 = partials + ((int64_t)blockIdx.x * 2) * E + q * 4;
+            *reinterpret_cast<float4*>(p0) = s0;
+            *reinterpret_cast<float4*>(p0 + E) = s1;
+        } else {
+            float* d0 = dtable + q * 4;
+            atomicAdd(d0 + 0, s0.x); atomicAdd(d0 + 1, s0.y); atomicAdd(d0 + 2, s0.z); atomicAdd(d0 + 3, s0.w);
+            if (V > 1) {
+                float* d1 = dtable + (int64_t)E + q * 4;
+                atomicAdd(d1 + 0, s1.x); atomicAdd(d1 + 1, s1.y); atomicAdd(d1 + 2, s1.z); atomicAdd(d1 + 3, s1.w);
+            }
         }
+    }
+    // the workgroup's table: one global atomic per occupied slot and element
+    for (int i = threadIdx.x; i < slots * E; i += 256) {
+        const int key = keys[i / E];
+        if (key >= 0) atomicAdd(dtable + (int64_t)key * E + (i % E), rows[i]);
+    }
+}
+
+// rows 0 and 1 of dtable += the workgroups' partial rows, in a fixed order: a workgroup owns 8 of the 2E elements,
+// 32 lanes per element each add every 32nd partial, the 32 lane sums are added in lane order
+__global__ __launch_bounds__(256) void embed_bwd_fold_kernel(const float* __restrict__ partials, int G, int E, int V,
+                                                             float* __restrict__ dtable) {
+    __shared__ float sh[32][8];
+    const int el = threadIdx.x & 7, part = threadIdx.x >> 3;
+    const int i = blockIdx.x * 8 + el;                  // 0 .. 2E-1: (row, element)
+    float s = 0.f;
+    if (i < 2 * E) {
+#pragma unroll 4
+        for (int g = part; g < G; g += 32) s += partials[(int64_t)g * 2 * E + i];
+    }
+    sh[part][el] = s;
+    __syncthreads();
+    if (part == 0 && i < 2 * E && !(i >= E && V < 2)) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 32; ++k) t += sh[k][el];
+        dtable[i] += t;
     }
 }
 
@@ -192,22 +253,62 @@ extern "C" int cutie_embed_fwd(const int32_t* ids, int64_t n_cells, const float*
     return CUTIE_OK;
 }
 
+namespace {
+struct EmbedBwdPlan { int groups, cells_per_wg, slots; size_t lds; };
+inline EmbedBwdPlan embed_bwd_plan(int64_t n_cells, int E) {
+    EmbedBwdPlan p;
+    // ~128 cells a workgroup, at most 1024 workgroups: short per-workgroup loops (the pass is latency-bound) now that
+    // the hot rows no longer cost one same-address atomic per workgroup
+    static const int cells = getenv("CUTIE_EMB_CELLS") ? atoi(getenv("CUTIE_EMB_CELLS")) : 128;      // dev knobs
+    static const int max_slots = getenv("CUTIE_EMB_SLOTS") ? atoi(getenv("CUTIE_EMB_SLOTS")) : 16;
+    int64_t g = cutie::cdiv(n_cells, cells);
+    if (g > 4096) g = 4096;
+    if (g < 1) g = 1;
+    p.groups = (int)g;
+    p.cells_per_wg = (int)cutie::cdiv(n_cells, g);
+    // 16 slots (8 KB of LDS rows at E = 128): a workgroup's 128 cells of a document grid hold about ten tokens, and
+    // clearing / flushing a larger table costs more than it saves (64 slots: +14 us on the bench batch)
+    p.slots = 32768 / (E * 4);
+    if (p.slots > max_slots) p.slots = max_slots;
+    p.lds = ((size_t)p.slots * 4 + 15) / 16 * 16 + (size_t)p.slots * E * 4;
+    return p;
+}
+}  // namespace
+
+extern "C" size_t cutie_embed_bwd_workspace_bytes(int64_t n_cells, int E) {
+    if (n_cells < 1 || E < 4) return 0;
+    return (size_t)embed_bwd_plan(n_cells, E).groups * 2 * E * sizeof(float);
+}
+
 extern "C" int cutie_embed_bwd(const int32_t* ids, int64_t n_cells, const void* dout, int ld_dout,
-                               int dout_dtype, float* dtable, int V, int E, cutie_stream_t stream_) {
+                               int dout_dtype, float* dtable, int V, int E, void* workspace, size_t workspace_bytes,
+                               cutie_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     CUTIE_CHECK_ARG(n_cells >= 0 && V >= 1 && E >= 4 && (E % 4) == 0 && E <= 1024, "embed_bwd: n_cells=%lld V=%d E=%d",
                     (long long)n_cells, V, E);
     CUTIE_CHECK_ARG(ld_dout >= E && (ld_dout % 4) == 0, "embed_bwd: ld_dout=%d", ld_dout);
     if (n_cells == 0) return CUTIE_OK;
     CUTIE_CHECK_ARG(ids && dout && dtable, "embed_bwd: null pointer");
-    // Measured at 131072 cells (profiles/r01_e): ~100 us whether 128, 256 or 512 workgroups run - the
-    // time goes to same-address atomics of the few most frequent dictionary ids (Zipf), not to the reads
-    const int cells_per_wg = 512;
-    const int g = (int)cutie::cdiv(n_cells, cells_per_wg);
+    const EmbedBwdPlan pl = embed_bwd_plan(n_cells, E);
+    float* partials = nullptr;
+    if (workspace) {
+        if (workspace_bytes < cutie_embed_bwd_workspace_bytes(n_cells, E) || !cutie::aligned16(workspace)) {
+            cutie::set_error("embed_bwd: workspace %zu < %zu (or not 16-byte aligned)", workspace_bytes,
+                             cutie_embed_bwd_workspace_bytes(n_cells, E));
+            return CUTIE_E_WORKSPACE;
+        }
+        partials = (float*)workspace;
+    }
     CUTIE_DISPATCH_DTYPE(dout_dtype, DT,
-        hipLaunchKernelGGL(embed_bwd_kernel<DT>, dim3(g), dim3(256), 0, stream, ids, n_cells,
-                           (const typename elem<DT>::type*)dout, ld_dout, dtable, V, E / 4, cells_per_wg));
+        hipLaunchKernelGGL(embed_bwd_kernel<DT>, dim3(pl.groups), dim3(256), pl.lds, stream, ids, n_cells,
+                           (const typename elem<DT>::type*)dout, ld_dout, dtable, V, E / 4, pl.cells_per_wg, partials,
+                           pl.slots));
     CUTIE_CHECK_LAUNCH();
+    if (partials) {
+        hipLaunchKernelGGL(embed_bwd_fold_kernel, dim3((2 * E + 7) / 8), dim3(256), 0, stream, partials, pl.groups, E, V,
+                           dtable);
+        CUTIE_CHECK_LAUNCH();
+    }
     return CUTIE_OK;
 }
 

@@ -53,10 +53,16 @@ def embed_fwd(ids, table, out, oob):
     return out
 
 
-def embed_bwd(ids, dout, dtable):
+def embed_bwd_workspace_bytes(n_cells, E):
+    return capi.lib().cutie_embed_bwd_workspace_bytes(int(n_cells), int(E))
+
+
+def embed_bwd(ids, dout, dtable, workspace=None):
+    """workspace: optional uint8 tensor of embed_bwd_workspace_bytes(ids.numel(), E) bytes - with it the two hot rows
+    (ids 0 and 1) are folded in a fixed order instead of by atomics"""
     V, E = dtable.shape
     call("cutie_embed_bwd", ptr(ids), ids.numel(), ptr(dout), ld_of(dout), dt_of(dout), ptr(dtable), V, E,
-         stream())
+         ptr(workspace), workspace.numel() * workspace.element_size() if workspace is not None else 0, stream())
     return dtable
 
 

@@ -463,7 +463,10 @@ class Engine(object):
                 self._backprop_into(P, n)
             elif n.op == "embed":
                 self._backprop_into(P, n)
-                ops.embed_bwd(P.grid, P.dy[n.name][..., :n.channels], self.grads[n.name + "/weights"])
+                if getattr(P, "embed_ws", None) is None:
+                    P.embed_ws = torch.empty(ops.embed_bwd_workspace_bytes(P.grid.numel(), n.channels), dtype=torch.uint8,
+                                             device=self.dev)
+                ops.embed_bwd(P.grid, P.dy[n.name][..., :n.channels], self.grads[n.name + "/weights"], P.embed_ws)
                 P.d_embed = P.dy[n.name]
         if side is not None:
             main.wait_stream(side)     # every weight gradient is in place; the buffers it read may be reused

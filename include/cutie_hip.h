@@ -88,9 +88,15 @@ int cutie_embed_fwd(const int32_t* ids, int64_t n_cells, const float* table, int
 
 /* backward of K1: dtable[ids[cell], :] += dout[cell, :]  (f32 accumulate; dtable is NOT
  * cleared here).  This is the scatter-add TF applies to the IndexedSlices gradient.
- * Ids 0 and 1 ([PAD] = empty cell, [UNK]) are pre-reduced per workgroup before the atomics. */
+ * Same-address float atomics are what bounds it, so ids 0 and 1 ([PAD] = empty cell, [UNK]) are summed per
+ * workgroup in registers and every other id per workgroup in an LDS table before anything reaches the table.
+ * workspace (nullable, cutie_embed_bwd_workspace_bytes(n_cells, E) bytes, 16-byte aligned, clobbered): with it the
+ * workgroups' partial rows for ids 0 and 1 are stored and folded in a fixed order (no atomics on the two hot rows,
+ * the same bits every run); without it they are added atomically, one add per workgroup and element. */
+size_t cutie_embed_bwd_workspace_bytes(int64_t n_cells, int E);
 int cutie_embed_bwd(const int32_t* ids, int64_t n_cells, const void* dout, int ld_dout,
-                    int dout_dtype, float* dtable, int V, int E, cutie_stream_t stream);
+                    int dout_dtype, float* dtable, int V, int E,
+                    void* workspace, size_t workspace_bytes, cutie_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------
  * K2-K5  stride-1 SAME (dilated) cross-correlation as an implicit GEMM on MFMA, with the

@@ -149,6 +149,24 @@ def test_embed_fwd_bwd(ops, dt):
     refg = torch.zeros((V, E), dtype=torch.float64)
     refg.index_add_(0, ids[valid].long(), dout[valid].double())
     assert relerr(dtab, refg) < 1e-5
+    # with the workspace: rows 0 and 1 folded in a fixed order - the same bits every run
+    ws = torch.empty(ops.embed_bwd_workspace_bytes(n, E), dtype=torch.uint8, device=DEV)
+    got = []
+    for _ in range(2):
+        dtab.zero_()
+        ops.embed_bwd(ids.to(DEV), dout.to(DEV), dtab, ws)
+        got.append(dtab.clone())
+    assert relerr(got[0], refg) < 1e-5
+    assert torch.equal(got[0][:2], got[1][:2])
+    # more distinct ids per workgroup than its LDS table holds (the overflow adds straight into the table),
+    # and one id that every cell of a workgroup shares
+    for ids2 in (torch.arange(n, dtype=torch.int32) % (V - 2) + 2,
+                 torch.where(torch.arange(n) % 3 == 0, torch.full((n,), 7), torch.arange(n) % 5).to(torch.int32)):
+        dtab.zero_()
+        ops.embed_bwd(ids2.to(DEV), dout.to(DEV), dtab, ws)
+        refg = torch.zeros((V, E), dtype=torch.float64)
+        refg.index_add_(0, ids2.long(), dout.double())
+        assert relerr(dtab, refg) < 1e-5
 
 
 # ------------------------------------------------------------------------------------ K2-K5
