@@ -49,7 +49,8 @@ __global__ __launch_bounds__(GB_NT) void grid_build_kernel(GridArgs a) {
     const int rows = a.rows, cols = a.cols;
     int32_t* g = lds;                       // [rows*cols]
     int32_t* row_start = lds + rows * cols; // [rows]
-    int32_t* flag = row_start + rows;       // [1] (+ pad to 8 bytes)
+    int32_t* row_cnt = row_start + rows;    // [rows]
+    int32_t* flag = row_cnt + rows;         // [1] (+ pad to 8 bytes)
 
     const int doc = blockIdx.x;
     const int t0 = a.doc_off[doc];
@@ -59,13 +60,19 @@ __global__ __launch_bounds__(GB_NT) void grid_build_kernel(GridArgs a) {
     // per-token scratch (keys, ids, sorted order): in LDS when the document fits the reserved
     // capacity (every lane re-reads all keys in the rank loop), else in the caller's workspace
     const bool in_lds = n <= a.cap;
-    char* kbase = reinterpret_cast<char*>(lds) + (((size_t)(rows * cols + rows + 2) * 4 + 7) & ~(size_t)7);
+    char* kbase = reinterpret_cast<char*>(lds) + (((size_t)(rows * cols + 2 * rows + 2) * 4 + 7) & ~(size_t)7);
     double* key_v = in_lds ? reinterpret_cast<double*>(kbase) : a.key_v + t0;
     double* key_h = in_lds ? key_v + a.cap : a.key_h + t0;
     int32_t* key_row = in_lds ? reinterpret_cast<int32_t*>(key_h + a.cap) : a.key_row + t0;
     int32_t* key_col = in_lds ? key_row + a.cap : a.key_col + t0;
     int32_t* key_id = in_lds ? key_col + a.cap : const_cast<int32_t*>(a.tok_id) + t0;
     int32_t* order = in_lds ? key_id + a.cap : a.tok_order + t0;
+    // what the placement lanes need per token besides the keys: in LDS too, so that the sequential walk
+    // of a row never waits for a global load
+    int32_t* t_ecid = in_lds ? order + a.cap : nullptr;
+    int32_t* t_px = in_lds ? t_ecid + a.cap : nullptr;
+    int32_t* t_py = in_lds ? t_px + a.cap : nullptr;
+    int32_t* members = in_lds ? t_py + a.cap : nullptr;     // token indices grouped by grid row
 
     // the document's output cells start at zero (the barrier below orders these stores before the
     // placement lanes' stores to the same cells)
@@ -78,7 +85,7 @@ __global__ __launch_bounds__(GB_NT) void grid_build_kernel(GridArgs a) {
             a.ps_y[c0 + i] = 0;
         }
     }
-    for (int i = tid; i < rows; i += GB_NT) row_start[i] = -1;
+    for (int i = tid; i < rows; i += GB_NT) { row_start[i] = -1; row_cnt[i] = 0; }
     if (tid == 0) *flag = 0;
     __syncthreads();
 
@@ -108,7 +115,12 @@ __global__ __launch_bounds__(GB_NT) void grid_build_kernel(GridArgs a) {
         key_h[i] = h_c;
         key_row[i] = row;
         key_col[i] = col;
-        if (in_lds) key_id[i] = a.tok_id[t0 + i];
+        if (in_lds) {
+            key_id[i] = a.tok_id[t0 + i];
+            t_ecid[i] = a.tok_ecid[t0 + i];
+            t_px[i] = x_left;
+            t_py[i] = (int)((double)y_top + (double)(y_bottom - y_top) / 2.0);
+        }
     }
     __syncthreads();  // workgroup-scope fence: the keys are re-read below by other lanes
     if (*flag) {
@@ -122,26 +134,66 @@ __global__ __launch_bounds__(GB_NT) void grid_build_kernel(GridArgs a) {
         return;
     }
 
-    // ---- stable sort (:507) as a rank by counting; all lanes read key j together (broadcast)
-    for (int i = tid; i < n; i += GB_NT) {
-        const int ri = key_row[i];
-        const double vi = key_v[i], hi = key_h[i];
-        const int di = key_id[i];
-        int rank = 0;
-#pragma unroll 4
-        for (int j = 0; j < n; ++j) {
-            rank += key_less(key_row[j], key_v[j], key_h[j], key_id[j], j, ri, vi, hi, di, i) ? 1 : 0;
+    // ---- stable sort (:507) as a rank by counting over the total order (row, v_c, h_c, dict_id, input index)
+    if (in_lds) {
+        // The row is the leading key, so a token's rank is (tokens in earlier rows) + (its rank inside its own row):
+        // group the tokens by row first and compare each only with its row mates - about n * (tokens per row)
+        // comparisons instead of n * n, which on ONE compute unit was 70 of this kernel's 113 us.
+        __shared__ int wave_tot[GB_NT / 64];
+        for (int i = tid; i < n; i += GB_NT) order[i] = atomicAdd(&row_cnt[key_row[i]], 1);   // slot inside the row's group
+        __syncthreads();
+        // exclusive scan of the row populations (rows <= 1024 = one lane each)
+        const int lane = tid & 63, wave = tid >> 6;
+        const int cnt = tid < rows ? row_cnt[tid] : 0;
+        int incl = cnt;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int up = __shfl_up(incl, d, 64);
+            if (lane >= d) incl += up;
         }
-        order[rank] = i;
-    }
-    __syncthreads();
+        if (lane == 63) wave_tot[wave] = incl;
+        __syncthreads();
+        int off = incl - cnt;
+        for (int w = 0; w < wave; ++w) off += wave_tot[w];
+        if (tid < rows && cnt > 0) row_start[tid] = off;      // first sorted position of the row
+        __syncthreads();
+        for (int i = tid; i < n; i += GB_NT) members[row_start[key_row[i]] + order[i]] = i;
+        __syncthreads();
+        for (int i = tid; i < n; i += GB_NT) {
+            const int ri = key_row[i];
+            const double vi = key_v[i], hi = key_h[i];
+            const int di = key_id[i];
+            const int m0 = row_start[ri], m1 = m0 + row_cnt[ri];
+            int rank = m0;
+            for (int m = m0; m < m1; ++m) {
+                const int j = members[m];
+                rank += key_less(ri, key_v[j], key_h[j], key_id[j], j, ri, vi, hi, di, i) ? 1 : 0;
+            }
+            order[rank] = i;      // the slots kept in order[] were all read before the barrier above
+        }
+        __syncthreads();
+    } else {
+        // a document too long for the LDS scratch: all lanes read key j together (broadcast), n * n comparisons
+        for (int i = tid; i < n; i += GB_NT) {
+            const int ri = key_row[i];
+            const double vi = key_v[i], hi = key_h[i];
+            const int di = key_id[i];
+            int rank = 0;
+#pragma unroll 4
+            for (int j = 0; j < n; ++j) {
+                rank += key_less(key_row[j], key_v[j], key_h[j], key_id[j], j, ri, vi, hi, di, i) ? 1 : 0;
+            }
+            order[rank] = i;
+        }
+        __syncthreads();
 
-    // ---- first sorted position of every row
-    for (int p = tid; p < n; p += GB_NT) {
-        const int r = key_row[order[p]];
-        if (p == 0 || key_row[order[p - 1]] != r) row_start[r] = p;
+        // ---- first sorted position of every row
+        for (int p = tid; p < n; p += GB_NT) {
+            const int r = key_row[order[p]];
+            if (p == 0 || key_row[order[p - 1]] != r) row_start[r] = p;
+        }
+        __syncthreads();
     }
-    __syncthreads();
 
     // ---- one lane per row replays the sequential placement (:508-557)
     const size_t cell0 = (size_t)doc * rows * cols;
@@ -170,13 +222,19 @@ __global__ __launch_bounds__(GB_NT) void grid_build_kernel(GridArgs a) {
             }
             if (write) {
                 gr[col] = dict_id;
-                a.labels[cell0 + r * cols + col] = (int8_t)a.tok_ecid[t0 + i];  // int8 wrap
+                a.labels[cell0 + r * cols + col] = (int8_t)(in_lds ? t_ecid[i] : a.tok_ecid[t0 + i]);  // int8 wrap
                 if (a.strategy != 0) {
-                    const int x_left = a.tok_box[(t0 + i) * 4 + 0], y_top = a.tok_box[(t0 + i) * 4 + 1];
-                    const int y_bottom = a.tok_box[(t0 + i) * 4 + 3];
-                    const double box_y = (double)y_top + (double)(y_bottom - y_top) / 2.0;
-                    a.ps_x[cell0 + r * cols + col] = x_left;
-                    a.ps_y[cell0 + r * cols + col] = (int)box_y;
+                    int px, py;
+                    if (in_lds) {
+                        px = t_px[i];
+                        py = t_py[i];
+                    } else {
+                        const int y_top = a.tok_box[(t0 + i) * 4 + 1], y_bottom = a.tok_box[(t0 + i) * 4 + 3];
+                        px = a.tok_box[(t0 + i) * 4 + 0];
+                        py = (int)((double)y_top + (double)(y_bottom - y_top) / 2.0);
+                    }
+                    a.ps_x[cell0 + r * cols + col] = px;
+                    a.ps_y[cell0 + r * cols + col] = py;
                 }
                 a.tok_place[(t0 + p) * 2 + 0] = r;
                 a.tok_place[(t0 + p) * 2 + 1] = col;
@@ -216,8 +274,8 @@ extern "C" int cutie_grid_build(const int32_t* tok_box, const int32_t* tok_id, c
     // it never moves and `cols` never grows: its outputs are strategy 1's.  The reference itself
     // confirms it on every fixture document (tests/golden/strategy2_cases.json).
     if (strategy == 2) strategy = 1;
-    const size_t lds_bytes = ((size_t)rows * cols + rows + 2) * sizeof(int32_t);
-    CUTIE_CHECK_ARG(lds_bytes <= 160 * 1024, "grid_build: %dx%d grid needs %zu B of LDS (max 163840)", rows,
+    const size_t lds_bytes = ((size_t)rows * cols + 2 * (size_t)rows + 2) * sizeof(int32_t);
+    CUTIE_CHECK_ARG(lds_bytes + 64 <= 160 * 1024, "grid_build: %dx%d grid needs %zu B of LDS (max 163776)", rows,
                     cols, lds_bytes);
     if (n_docs == 0) return CUTIE_OK;
     CUTIE_CHECK_ARG(grid && labels && ps_x && ps_y && tok_order && tok_place && status && doc_off && doc_extent,
@@ -242,12 +300,12 @@ extern "C" int cutie_grid_build(const int32_t* tok_box, const int32_t* tok_id, c
     a.key_row = (int32_t*)(a.key_h + t);
     a.key_col = a.key_row + t;
 
-    // per-token scratch in LDS: 32 bytes a token, up to 2048 tokens a document or what is left
+    // per-token scratch in LDS: 48 bytes a token, up to 2048 tokens a document or what is left
     const size_t grid_part = (lds_bytes + 7) & ~(size_t)7;
-    size_t cap = (160 * 1024 - grid_part) / 32;
+    size_t cap = (160 * 1024 - 64 - grid_part) / 48;       // 64: the kernel's static wave totals
     if (cap > 2048) cap = 2048;
     a.cap = (int)cap;
-    const size_t lds_total = grid_part + cap * 32;
+    const size_t lds_total = grid_part + cap * 48;
     CUTIE_CHECK_HIP(hipFuncSetAttribute((const void*)grid_build_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                         (int)lds_total));
     hipLaunchKernelGGL(grid_build_kernel, dim3(n_docs), dim3(GB_NT), lds_total, stream, a);

@@ -65,7 +65,7 @@ const char* cutie_last_error(void);
  *                 gets an all-zero grid / labels / ps and -1 in its tok_order / tok_place.
  *            Every element of every output is written by the call (nothing to pre-fill).
  * workspace  cutie_grid_build_workspace_bytes(T) bytes.
- * limits     rows*cols*4 bytes must fit the 160 KB LDS (<= 36864 cells), rows <= 1024.
+ * limits     (rows*cols + 2*rows + 2)*4 + 64 bytes must fit the 160 KB LDS (about 40000 cells), rows <= 1024.
  */
 size_t cutie_grid_build_workspace_bytes(int n_tokens);
 int cutie_grid_build(const int32_t* tok_box, const int32_t* tok_id, const int32_t* tok_ecid,

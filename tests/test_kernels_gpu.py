@@ -116,6 +116,31 @@ def test_grid_build_edges(ops):
     np.testing.assert_array_equal(out["labels"][2], ref["labels"][1])
 
 
+@pytest.mark.parametrize("strategy", [0, 1])
+def test_grid_build_long_document(ops, strategy):
+    """2600 tokens in one document: more than the LDS token scratch holds (2048), so the builder keeps its keys in
+    the workspace and ranks by comparing all pairs; next to it a short document on the row-grouped path."""
+    rng = np.random.RandomState(5)
+    ext = [0, 0, 1500, 2100]
+
+    def doc(n):
+        toks = []
+        for _ in range(n):
+            x, y = int(rng.randint(0, 1400)), int(rng.randint(0, 2050))
+            toks.append({"box": [x, y, x + int(rng.randint(5, 90)), y + int(rng.randint(8, 40))], "extent": ext,
+                         "dict_id": int(rng.randint(0, 50)), "class_id": int(rng.randint(0, 18)), "entity_id": 0})
+        return toks
+    docs = [doc(2600), doc(300)]
+    out, off = run_grid(ops, docs, 64, 64, strategy, 18)
+    ref = go.positional_mapping(docs, 64, 64, strategy, 18)
+    assert out["status"].tolist() == [0, 0]
+    np.testing.assert_array_equal(out["grid"], ref["grid"])
+    np.testing.assert_array_equal(out["labels"], ref["labels"])
+    for d in range(2):
+        assert out["order"][off[d]:off[d + 1]].tolist() == ref["order"][d]
+        assert [tuple(p) for p in out["place"][off[d]:off[d + 1]].tolist()] == ref["placed"][d]
+
+
 # ------------------------------------------------------------------------------------ K1
 @pytest.mark.parametrize("dt", ["f32", "bf16", "f16"])
 def test_embed_fwd_bwd(ops, dt):
