@@ -214,8 +214,9 @@ def main():
                                "frac": round(ach / peak, 4), "traffic": traffic, "traffic_source": traffic_src,
                                "kernel": "conv_wide_kernel + conv_kernel (forward + data-gradient implicit GEMM)", "launches": n,
                                "avg_launch_ms": round(ms / max(n, 1), 4),
-                               "timed_steps": "every %d-th of the %d timed steps, run on one stream (the others run the weight "
-                                              "gradients on a second stream)" % (ConvTimer.EVERY, args.steps),
+                               "timed_steps": "every %d-th of the %d timed steps%s" % (
+                                   ConvTimer.EVERY, args.steps,
+                                   ", run on one stream (the others run the weight gradients on a second stream)" if overlap else ""),
                                "share_of_step": round(ms / max(1, -(-args.steps // ConvTimer.EVERY)) / (1e3 * dt / args.steps), 4)}
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(C, V, E, H, W, packed)

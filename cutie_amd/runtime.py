@@ -397,8 +397,11 @@ class Engine(object):
         squared global norm the way tf.clip_by_global_norm sees it.  Needs forward(labels=...).
 
         on_ready(upto): data-parallel hook.  The flat gradient buffer is laid out in backward
-        order, so after each conv's weight gradient (and its L2 term) the prefix [0, upto) is
-        final; the caller starts that slice's all-reduce while earlier layers still compute."""
+        order, so after each conv's weight gradient the prefix [0, upto) is final and the caller
+        starts that slice's all-reduce while earlier layers still compute.  With the hook the conv
+        range is left WITHOUT its L2 term (and, f16, still loss-scaled): the term is the same on
+        every rank, so it is added once after the reduce - add_l2_after_reduce() - instead of by
+        fourteen small launches inside backward."""
         if not P.has_labels:
             raise CutieError("loss_backward needs forward(..., labels=...)")
         self._plan_backward(P)
@@ -457,7 +460,6 @@ class Engine(object):
                                    a["kh"], a["kw"], a["rate"], self.grads[n.name + "/weights"], P.wgrad_ws)
                     if on_ready is not None:
                         off, cnt, _ = self.offsets[n.name + "/weights"]
-                        ops.l2_add(self.params_flat[off:off + cnt], self.grads_flat[off:off + cnt], wd, P.reg, P.scratch, ls)
                         on_ready(_pad(off + cnt, 64))
             elif n.op == "positional_sampling":
                 self._backprop_into(P, n)
@@ -480,12 +482,26 @@ class Engine(object):
         else:
             for rows, batches in P._sum_rows_batches:
                 ops.replay_sum_rows(batches, rows)
+        P.reg_div = 1.0
+        P.l2_pending = on_ready is not None
         if on_ready is None:
             ops.l2_add(self.params_flat[:self.n_conv_w], self.grads_flat[:self.n_conv_w], wd, P.reg, P.scratch, ls)
         if ls is not None:
             # biases and the embedding carry no L2 term: wd = 0 only takes the loss scale out
             ops.l2_add(self.params_flat[self.n_conv_w:], self.grads_flat[self.n_conv_w:], 0.0, P.reg, P.scratch, ls)
         return P
+
+    def add_l2_after_reduce(self, P, world=1):
+        """Data-parallel tail of loss_backward(on_ready=...): the conv range holds the SUM of the ranks' gradients;
+        the optimizer applies 1/world to everything, so the L2 term goes in as world * wd * w (and, f16, the loss
+        scale comes out) - mean gradient + wd * w, what every rank adding its own term before the reduce gives."""
+        if not getattr(P, "l2_pending", False):
+            return
+        wd = float(self.net.loss_spec["weight_decay"])
+        ops.l2_add(self.params_flat[:self.n_conv_w], self.grads_flat[:self.n_conv_w], wd * world, P.reg, P.scratch,
+                   self.loss_scale)
+        P.reg_div = float(world)       # the kernel's 0.5 * (world * wd) * sum(w^2) is world times the loss term
+        P.l2_pending = False
 
     def global_norm_sq(self, P, tf_indexed_slices=True):
         """Squared global norm.  With tf_indexed_slices (single replica, TF parity) the embedding
@@ -508,5 +524,5 @@ class Engine(object):
 
     def losses(self, P):
         """(model_loss, regularization_loss, total_loss) as python floats (one sync)."""
-        ml, rg = float(P.loss[0].item()), float(P.reg.item())
+        ml, rg = float(P.loss[0].item()), float(P.reg.item()) / getattr(P, "reg_div", 1.0)
         return ml, rg, ml + rg

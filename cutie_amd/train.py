@@ -54,6 +54,7 @@ class Trainer(object):
             # on the collective's stream under the remaining layers' dgrad/wgrad kernels
             eng.loss_backward(P, on_ready=self.buckets.ready)
             self.buckets.finish()
+            eng.add_l2_after_reduce(P, self.world)     # one launch over the reduced conv range
         else:
             eng.loss_backward(P)
         gn = eng.global_norm_sq(P, tf_indexed_slices=(self.world == 1))

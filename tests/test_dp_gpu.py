@@ -3,7 +3,7 @@
 The collectives themselves are covered on CPU (tests/test_parallel_gloo.py, gloo, world size 2) and
 by the driver's multi-GPU bench over RCCL; two ranks cannot share one GPU under RCCL, and gloo with
 device tensors dead-locked intermittently on a shared GPU, so no multi-process test runs here.
-What is checked: backward with the `on_ready` hook (per-layer L2 + prefix notifications, the path
+What is checked: backward with the `on_ready` hook (prefix notifications, L2 term after the reduce: the path
 every rank takes when world > 1) produces the gradients of the plain path, announces a growing
 prefix that ends at the conv range, and a bucket list built over it covers the buffer once."""
 import types
@@ -66,6 +66,7 @@ def test_backward_hook_path_matches_plain_path():
     P = eng.forward(grid, labels=labels)
     eng.loss_backward(P, on_ready=hook)
     buckets._launch(buckets.next_lo, eng.grads_flat.numel())         # what finish() sends last
+    eng.add_l2_after_reduce(P, 1)                                    # the L2 term follows the (here: absent) reduce
     torch.cuda.synchronize()
     hooked = eng.grads_flat.cpu().numpy()
 
