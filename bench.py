@@ -202,13 +202,13 @@ def main():
             ach = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
             peak = BF16_PEAK_TFLOPS if args.dtype in ("bf16", "f16") else 157.3    # f16 and bf16 MFMA run at one rate
             traffic, traffic_src = None, None
-            pmc = os.path.join(REPO, "profiles", "r01_f_pmc.json")
+            pmc = os.path.join(REPO, "profiles", "r01_g_pmc.json")
             if args.dtype == "bf16" and os.path.exists(pmc):      # PMC passes cannot run inside the timed bench
                 with open(pmc) as f:
                     k = json.load(f)["kernels"].get("conv_wide_kernel<1, 256>")
                 if k:
                     traffic = k["hbm_bytes_per_launch"]
-                    traffic_src = ("profiles/r01_f_pmc.json: (2*FETCH_SIZE + WRITE_SIZE)*1024 per conv_wide_kernel<bf16,256> launch "
+                    traffic_src = ("profiles/r01_g_pmc.json: (2*FETCH_SIZE + WRITE_SIZE)*1024 per conv_wide_kernel<bf16,256> launch "
                                    "(tools/gpu_pmc.sh); algorithmic bytes 136 MB forward, 203 MB data gradient with the fused norm sums")
             out["roofline"] = {"bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
                                "frac": round(ach / peak, 4), "traffic": traffic, "traffic_source": traffic_src,
