@@ -436,6 +436,10 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradParams p) {
 //   Staging is LDS-DMA (`buffer_load_dwordx4 ... lds`, 1-KB pieces of 4 pixel rows, the swizzle
 //   applied on the source address): the pieces of row r+1 are sent off between the taps of row
 //   r's first K block and land in the other half of the LDS image; one barrier per row.
+//   KW = 1 (1x1 layers) has no taps to share a patch between, so there the "tap" index walks TWO cin tiles
+//   instead: a workgroup owns 256 cin x 128 cout, stages both 128-channel patches of a row (2 x 16 KB, the
+//   space one haloed patch takes) and gets 32 MFMAs out of a staged row instead of 16 (1024 -> 256: 141 -> see
+//   DESIGN.md).
 //   MASK >= 0: bit ks*KW+t says whether K block ks of tap t overlaps the image - a compile-time
 //   pattern (all ten for W = 64 and dilation <= 8; eight for dilation 16) that leaves the row loop
 //   branch-free so the compiler can pipeline it; MASK < 0 is the general instance (uniform tests).
@@ -460,6 +464,10 @@ template <int DT, int KW, int MASK>
 __global__ __launch_bounds__(WG5_NT, 2) void wgrad5_kernel(Wgrad5Params p) {
     constexpr int ES = 2;
     constexpr int ROWB = 256;       // bytes per staged pixel row: 128 channels
+    constexpr bool TWO = KW == 1;   // two cin tiles per workgroup in place of taps
+    constexpr int NT_ = TWO ? 2 : KW;        // accumulator sets: taps, or cin tiles
+    constexpr int NX = TWO ? 4 : 3;          // x pieces per wave and row
+    constexpr int NPC = NX + 2;              // + the two dz pieces
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int pwx = WG5_PIX + 2 * p.pad;                    // patch rows that hold data
 
@@ -485,16 +493,16 @@ __global__ __launch_bounds__(WG5_NT, 2) void wgrad5_kernel(Wgrad5Params p) {
     const int mt = bid % p.mt;
     const int ti = bid / p.mt;                 // tap row
     const int sy = (ti - p.kh / 2) * dil;
-    const int m0 = mt * 128, n0 = nt * 128;
+    const int m0 = mt * (TWO ? 256 : 128), n0 = nt * 128;
 
     const int units_total = p.B * H * p.nwseg;  // a unit = (sample, image row, 64-pixel column segment)
     const int per = (units_total + p.splits - 1) / p.splits;
     const int unit_begin = split * per;
     const int unit_end = min(units_total, unit_begin + per);
 
-    float4_t acc[KW][2][4];
+    float4_t acc[NT_][2][4];
 #pragma unroll
-    for (int t = 0; t < KW; ++t)
+    for (int t = 0; t < NT_; ++t)
 #pragma unroll
         for (int m = 0; m < 2; ++m)
 #pragma unroll
@@ -511,12 +519,13 @@ __global__ __launch_bounds__(WG5_NT, 2) void wgrad5_kernel(Wgrad5Params p) {
     // channel chunk ((s >> 1) ^ tr_func(row)) * 2 + (s & 1): the swizzle the transposed reads
     // below expect, applied on the SOURCE address.  Rows past the patch get zeros.
     const int prow = lane >> 4, pslot = lane & 15;
-    int x_r[3], x_off[3], d_r[2], d_off[2];
-    bool x_ok[3], d_ok[2];
+    int x_r[NX], x_off[NX], d_r[2], d_off[2];
+    bool x_ok[NX], d_ok[2];
 #pragma unroll
-    for (int u = 0; u < 3; ++u) {
-        x_r[u] = (wave + 8 * u) * 4 + prow;
-        const int chn = m0 + ((((pslot >> 1) ^ tr_func(x_r[u])) << 1) | (pslot & 1)) * 8;
+    for (int u = 0; u < NX; ++u) {
+        // TWO: pieces 0, 1 are the 64 rows of cin tile 0, pieces 2, 3 those of cin tile 1
+        x_r[u] = (wave + 8 * (TWO ? (u & 1) : u)) * 4 + prow;
+        const int chn = m0 + (TWO ? (u >> 1) * 128 : 0) + ((((pslot >> 1) ^ tr_func(x_r[u])) << 1) | (pslot & 1)) * 8;
         x_ok[u] = x_r[u] < pwx && chn < p.cin;
         x_off[u] = ((x_r[u] - pad) * p.ld_x + chn) * ES;
     }
@@ -537,14 +546,15 @@ __global__ __launch_bounds__(WG5_NT, 2) void wgrad5_kernel(Wgrad5Params p) {
         const int hh = h + sy;
         return hh >= 0 && hh < H;
     };
-    auto issue_piece = [&](int k, int b, int h, int ws, int bsel, bool live) {    // k = 0..4, compile-time at every call
-        if (k < 3) {
+    auto issue_piece = [&](int k, int b, int h, int ws, int bsel, bool live) {    // k = 0..NPC-1, compile-time at every call
+        if (k < NX) {
             const int w = ws - pad + x_r[k];
             const bool ok = live && x_ok[k] && w >= 0 && w < W;
-            glds16(rsrc_x, lds0 + bsel * WG5_XSTRIDE + (wave + 8 * k) * 1024,
+            const int piece = TWO ? (k >> 1) * 16 + wave + 8 * (k & 1) : wave + 8 * k;      // 1-KB slot in the x image
+            glds16(rsrc_x, lds0 + bsel * WG5_XSTRIDE + piece * 1024,
                    ok ? (unsigned)(((b * H + h + sy) * W + ws) * p.ld_x * ES + x_off[k]) : BUF_OOB);
         } else {
-            const int u = k - 3;
+            const int u = k - NX;
             const bool ok = live && d_ok[u] && ws + d_r[u] < W;
             glds16(rsrc_d, lds0 + WG5_D0 + bsel * WG5_DBUF + (wave + 8 * u) * 1024,
                    ok ? (unsigned)(((b * H + h) * W + ws) * p.ld_dz * ES + d_off[u]) : BUF_OOB);
@@ -562,12 +572,13 @@ __global__ __launch_bounds__(WG5_NT, 2) void wgrad5_kernel(Wgrad5Params p) {
     const int q = li >> 2, pp = li & 3;
     const int r1 = lg * 8 + q;
     unsigned da = lds0 + WG5_D0 + r1 * ROWB + (((wn * 4) ^ tr_func(r1)) * 32) + pp * 8;   // hi row = + 4 rows
-    unsigned xa[KW][2];
+    unsigned xa[NT_][2];
 #pragma unroll
-    for (int t = 0; t < KW; ++t) {
-        const int x1 = pad + (t - KW / 2) * dil + r1, x2 = x1 + 4;
-        xa[t][0] = lds0 + x1 * ROWB + (((wm * 2) ^ tr_func(x1)) * 32) + pp * 8;
-        xa[t][1] = lds0 + x2 * ROWB + (((wm * 2) ^ tr_func(x2)) * 32) + pp * 8;
+    for (int t = 0; t < NT_; ++t) {
+        const int x1 = pad + (TWO ? 0 : (t - KW / 2) * dil) + r1, x2 = x1 + 4;
+        const unsigned tile = TWO ? t * 16384u : 0u;        // the second cin tile's patch sits 16 KB further on
+        xa[t][0] = lds0 + tile + x1 * ROWB + (((wm * 2) ^ tr_func(x1)) * 32) + pp * 8;
+        xa[t][1] = lds0 + tile + x2 * ROWB + (((wm * 2) ^ tr_func(x2)) * 32) + pp * 8;
     }
     auto tr2 = [&](unsigned lo, unsigned hi) {
         const short4_t a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4_t*)(uintptr_t)(lo));
@@ -580,7 +591,7 @@ __global__ __launch_bounds__(WG5_NT, 2) void wgrad5_kernel(Wgrad5Params p) {
     int buf = 0;
     if (cur < unit_end) {
 #pragma unroll
-        for (int k = 0; k < 5; ++k) issue_piece(k, cb, ch, cws, 0, true);
+        for (int k = 0; k < NPC; ++k) issue_piece(k, cb, ch, cws, 0, true);
     }
     while (cur < unit_end) {
         int nb, nh, nws;
@@ -596,7 +607,7 @@ __global__ __launch_bounds__(WG5_NT, 2) void wgrad5_kernel(Wgrad5Params p) {
             if (MASK < 0 && px0 >= W) {
                 if (ks == 0) {
 #pragma unroll
-                    for (int k = 0; k < 5; ++k) issue_piece(k, nb, nh, nws, buf ^ 1, more);
+                    for (int k = 0; k < NPC; ++k) issue_piece(k, nb, nh, nws, buf ^ 1, more);
                 }
                 continue;
             }
@@ -604,13 +615,13 @@ __global__ __launch_bounds__(WG5_NT, 2) void wgrad5_kernel(Wgrad5Params p) {
 #pragma unroll
             for (int n = 0; n < 4; ++n) bf[n] = tr2((da ^ (n * 32)) + ks * 32 * ROWB, (da ^ (n * 32)) + ks * 32 * ROWB + 4 * ROWB);
 #pragma unroll
-            for (int t = 0; t < KW; ++t) {
+            for (int t = 0; t < NT_; ++t) {
                 if (ks == 0) {
 #pragma unroll
-                    for (int k = 0; k < 5; ++k)
-                        if (k * KW / 5 == t) issue_piece(k, nb, nh, nws, buf ^ 1, more);
+                    for (int k = 0; k < NPC; ++k)
+                        if (k * NT_ / NPC == t) issue_piece(k, nb, nh, nws, buf ^ 1, more);
                 }
-                const int sx = (t - KW / 2) * dil;
+                const int sx = TWO ? 0 : (t - KW / 2) * dil;
                 // input pixels px0+sx .. px0+sx+31 all outside the image: nothing to add (uniform)
                 if (MASK >= 0 && !((MASK >> (ks * KW + t)) & 1)) continue;     // compile-time pattern
                 if (MASK < 0 && (px0 + sx + 31 < 0 || px0 + sx >= W)) continue;
@@ -630,21 +641,21 @@ __global__ __launch_bounds__(WG5_NT, 2) void wgrad5_kernel(Wgrad5Params p) {
         buf ^= 1;
         da += dda;
 #pragma unroll
-        for (int t = 0; t < KW; ++t) { xa[t][0] += dxa; xa[t][1] += dxa; }
+        for (int t = 0; t < NT_; ++t) { xa[t][0] += dxa; xa[t][1] += dxa; }
         cur = nxt; cb = nb; ch = nh; cws = nws;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the last row's (all-zero) prefetch
 
 #pragma unroll
-    for (int t = 0; t < KW; ++t) {
-        float* slab = p.slabs + ((long long)split * p.kh * KW + (ti * KW + t)) * p.cin * p.cout;
+    for (int t = 0; t < NT_; ++t) {
+        float* slab = p.slabs + ((long long)split * p.kh * KW + (TWO ? ti : ti * KW + t)) * p.cin * p.cout;
 #pragma unroll
         for (int m = 0; m < 2; ++m)
 #pragma unroll
             for (int n = 0; n < 4; ++n)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int ci = m0 + (wm * 2 + m) * 16 + lg * 4 + r;
+                    const int ci = m0 + (TWO ? t * 128 : 0) + (wm * 2 + m) * 16 + lg * 4 + r;
                     const int co = n0 + (wn * 4 + n) * 16 + li;
                     if (ci < p.cin && co < p.cout) slab[(long long)ci * p.cout + co] = acc[t][m][n][r];
                 }
@@ -685,8 +696,8 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     }
 }
 
-inline int wgrad5_splits(int B, int H, int W, int cin, int cout, int kh) {
-    const long long groups = (long long)kh * cutie::cdiv(cin, 128) * cutie::cdiv(cout, 128);
+inline int wgrad5_splits(int B, int H, int W, int cin, int cout, int kh, int kw) {
+    const long long groups = (long long)kh * cutie::cdiv(cin, kw == 1 ? 256 : 128) * cutie::cdiv(cout, 128);
     long long s = 256 / groups;                 // about one 512-lane workgroup per CU
     const long long units = (long long)B * H * cutie::cdiv(W, WG5_PIX);
     if (s > units) s = units;
@@ -882,7 +893,7 @@ extern "C" int cutie_conv_dgrad_in_stats(const cutie_conv_seg* segs, int n_segs,
 extern "C" size_t cutie_conv_wgrad_workspace_bytes(int B, int H, int W, int cin, int cout, int kh, int kw) {
     if (B < 1 || H < 1 || W < 1 || cin < 1 || cout < 1 || kh < 1 || kw < 1) return 0;
     int s = wgrad_splits(B, H, cin, cout, kh * kw);
-    const int s5 = wgrad5_splits(B, H, W, cin, cout, kh);
+    const int s5 = wgrad5_splits(B, H, W, cin, cout, kh, kw);
     if (s5 > s) s = s5;
     return (size_t)s * kh * kw * cin * cout * sizeof(float);
 }
@@ -920,8 +931,8 @@ extern "C" int cutie_conv_wgrad(const void* x, int ld_x, int cin, const void* dz
         q.x = (const char*)x; q.dz = (const char*)dz; q.ld_x = ld_x; q.cin = cin; q.ld_dz = ld_dz; q.cout = cout;
         q.B = B; q.H = H; q.W = W; q.kh = kh; q.kw = kw; q.dil = dil;
         q.slabs = (float*)workspace;
-        q.splits = wgrad5_splits(B, H, W, cin, cout, kh);
-        q.mt = (int)cutie::cdiv(cin, 128);
+        q.splits = wgrad5_splits(B, H, W, cin, cout, kh, kw);
+        q.mt = (int)cutie::cdiv(cin, kw == 1 ? 256 : 128);
         q.ntile = (int)cutie::cdiv(cout, 128);
         q.nwseg = (int)cutie::cdiv(W, WG5_PIX);
         // halo columns: with one 64-pixel segment per row everything beyond the image is zero
