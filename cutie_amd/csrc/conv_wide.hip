@@ -15,7 +15,11 @@
 //   * one barrier per K step: wait for my own loads, barrier (everybody's loads have landed and
 //     everybody is done reading the other buffer), issue the next step's loads, compute;
 //   * a tap whose shifted tile lies wholly outside the image is not a step at all (uniform for
-//     the workgroup), which keeps the in-bounds FLOP accounting for 16-aligned dilations.
+//     the workgroup), which keeps the in-bounds FLOP accounting for 16-aligned dilations; since that makes
+//     the tiles of a dilated layer unequal, an XCD takes its samples' tiles heaviest first (plan_tile_order);
+//   * epilogue: bias + activation, the tile's instance-norm moments STORED into the tile's slot, and - for a
+//     data gradient into an instance-normalised layer - that layer's backward sums (sum dy, sum dy * xhat)
+//     taken in the same store pass (ConvParams::bw_*), so no separate reduction pass reads dy and a again.
 #include "conv_common.h"
 #include <stdlib.h>
 
