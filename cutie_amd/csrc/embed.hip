@@ -2,7 +2,6 @@
 // All HBM-bound row copies: one lane moves 4 consecutive elements, a row is read by
 // consecutive lanes (model_framework.py:43-54, :73-86).
 #include "common.h"
-#include <stdlib.h>
 
 namespace {
 using namespace cutie;
@@ -259,8 +258,7 @@ inline EmbedBwdPlan embed_bwd_plan(int64_t n_cells, int E) {
     EmbedBwdPlan p;
     // ~128 cells a workgroup, at most 1024 workgroups: short per-workgroup loops (the pass is latency-bound) now that
     // the hot rows no longer cost one same-address atomic per workgroup
-    static const int cells = getenv("CUTIE_EMB_CELLS") ? atoi(getenv("CUTIE_EMB_CELLS")) : 128;      // dev knobs
-    static const int max_slots = getenv("CUTIE_EMB_SLOTS") ? atoi(getenv("CUTIE_EMB_SLOTS")) : 16;
+    constexpr int cells = 128, max_slots = 16;
     int64_t g = cutie::cdiv(n_cells, cells);
     if (g > 4096) g = 4096;
     if (g < 1) g = 1;

@@ -6,7 +6,6 @@
 // a workgroup covers `rows_par` pixels side by side and walks a slice of HW, so every
 // per-(b,c) reduction is: registers -> LDS across the side-by-side rows -> one f32 atomic.
 #include "common.h"
-#include <stdlib.h>
 
 namespace {
 using namespace cutie;
@@ -362,10 +361,11 @@ inline int check_common(const char* name, int B, int HW, int C, int vec) {
 }
 inline dim3 reduce_grid(int B, int HW, int C, int vec) {
     const int rows_par = 256 / (C / vec);
-    static const int iters = getenv("CUTIE_NORM_ITERS") ? atoi(getenv("CUTIE_NORM_ITERS")) : 8;   // dev knob
-    int s = HW / (rows_par * iters);
-    static const int total = getenv("CUTIE_NORM_WGS") ? atoi(getenv("CUTIE_NORM_WGS")) : 1024;   // dev knob
-    const int cap = (total + B - 1) / (B > 0 ? B : 1);
+    // 8 row groups a workgroup and at most ~1024 workgroups: measured best on the MI355X (tools/norm_bench.py) -
+    // more, shorter workgroups pay the slot fold more often (2x as many: the same; 4x: 1.2x slower; 8x: 1.7x), half as
+    // many lose bandwidth (1.2x slower)
+    int s = HW / (rows_par * 8);
+    const int cap = (1024 + B - 1) / (B > 0 ? B : 1);
     if (s > cap) s = cap;
     if (s < 1) s = 1;
     return dim3(s, B);
