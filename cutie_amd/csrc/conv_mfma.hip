@@ -460,9 +460,12 @@ struct Wgrad5Params {
     int splits, mt, ntile, nwseg, pad;   // pad = halo columns staged on each side (clipped)
 };
 
-template <int DT, int KW, int MASK>
+//   NARROW (cout <= 64, one cout tile): the eight waves are 8 (cin) x 1 (cout) instead of 4 x 2 - a wave owns
+//   16 cin x 64 cout - so that no wave multiplies the padding half of a 128-wide cout tile.
+template <int DT, int KW, int MASK, bool NARROW = false>
 __global__ __launch_bounds__(WG5_NT, 2) void wgrad5_kernel(Wgrad5Params p) {
     constexpr int ES = 2;
+    constexpr int MBLK = NARROW ? 1 : 2;     // 16-channel cin blocks per wave
     constexpr int ROWB = 256;       // bytes per staged pixel row: 128 channels
     constexpr bool TWO = KW == 1;   // two cin tiles per workgroup in place of taps
     constexpr int NT_ = TWO ? 2 : KW;        // accumulator sets: taps, or cin tiles
@@ -474,7 +477,7 @@ __global__ __launch_bounds__(WG5_NT, 2) void wgrad5_kernel(Wgrad5Params p) {
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = NARROW ? wave : wave >> 1, wn = NARROW ? 0 : wave & 1;
     const int li = lane & 15, lg = lane >> 4;
     const int H = p.H, W = p.W, dil = p.dil, pad = p.pad;
 
@@ -500,11 +503,11 @@ __global__ __launch_bounds__(WG5_NT, 2) void wgrad5_kernel(Wgrad5Params p) {
     const int unit_begin = split * per;
     const int unit_end = min(units_total, unit_begin + per);
 
-    float4_t acc[NT_][2][4];
+    float4_t acc[NT_][MBLK][4];
 #pragma unroll
     for (int t = 0; t < NT_; ++t)
 #pragma unroll
-        for (int m = 0; m < 2; ++m)
+        for (int m = 0; m < MBLK; ++m)
 #pragma unroll
             for (int n = 0; n < 4; ++n) acc[t][m][n] = float4_t{0.f, 0.f, 0.f, 0.f};
 
@@ -577,8 +580,8 @@ __global__ __launch_bounds__(WG5_NT, 2) void wgrad5_kernel(Wgrad5Params p) {
     for (int t = 0; t < NT_; ++t) {
         const int x1 = pad + (TWO ? 0 : (t - KW / 2) * dil) + r1, x2 = x1 + 4;
         const unsigned tile = TWO ? t * 16384u : 0u;        // the second cin tile's patch sits 16 KB further on
-        xa[t][0] = lds0 + tile + x1 * ROWB + (((wm * 2) ^ tr_func(x1)) * 32) + pp * 8;
-        xa[t][1] = lds0 + tile + x2 * ROWB + (((wm * 2) ^ tr_func(x2)) * 32) + pp * 8;
+        xa[t][0] = lds0 + tile + x1 * ROWB + (((wm * MBLK) ^ tr_func(x1)) * 32) + pp * 8;
+        xa[t][1] = lds0 + tile + x2 * ROWB + (((wm * MBLK) ^ tr_func(x2)) * 32) + pp * 8;
     }
     auto tr2 = [&](unsigned lo, unsigned hi) {
         const short4_t a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4_t*)(uintptr_t)(lo));
@@ -625,12 +628,12 @@ __global__ __launch_bounds__(WG5_NT, 2) void wgrad5_kernel(Wgrad5Params p) {
                 // input pixels px0+sx .. px0+sx+31 all outside the image: nothing to add (uniform)
                 if (MASK >= 0 && !((MASK >> (ks * KW + t)) & 1)) continue;     // compile-time pattern
                 if (MASK < 0 && (px0 + sx + 31 < 0 || px0 + sx >= W)) continue;
-                short8_t af[2];
+                short8_t af[MBLK];
 #pragma unroll
-                for (int m = 0; m < 2; ++m)
+                for (int m = 0; m < MBLK; ++m)
                     af[m] = tr2((xa[t][0] ^ (m * 32)) + ks * 32 * ROWB, (xa[t][1] ^ (m * 32)) + ks * 32 * ROWB);
 #pragma unroll
-                for (int m = 0; m < 2; ++m)
+                for (int m = 0; m < MBLK; ++m)
 #pragma unroll
                     for (int n = 0; n < 4; ++n)
                         acc[t][m][n] = mma16<DT>(af[m], bf[n], acc[t][m][n]);
@@ -650,12 +653,12 @@ __global__ __launch_bounds__(WG5_NT, 2) void wgrad5_kernel(Wgrad5Params p) {
     for (int t = 0; t < NT_; ++t) {
         float* slab = p.slabs + ((long long)split * p.kh * KW + (TWO ? ti : ti * KW + t)) * p.cin * p.cout;
 #pragma unroll
-        for (int m = 0; m < 2; ++m)
+        for (int m = 0; m < MBLK; ++m)
 #pragma unroll
             for (int n = 0; n < 4; ++n)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int ci = m0 + (TWO ? t * 128 : 0) + (wm * 2 + m) * 16 + lg * 4 + r;
+                    const int ci = m0 + (TWO ? t * 128 : 0) + (wm * MBLK + m) * 16 + lg * 4 + r;
                     const int co = n0 + (wn * 4 + n) * 16 + li;
                     if (ci < p.cin && co < p.cout) slab[(long long)ci * p.cout + co] = acc[t][m][n][r];
                 }
@@ -958,22 +961,28 @@ extern "C" int cutie_conv_wgrad(const void* x, int ld_x, int cin, const void* dz
                     }
             }
             const dim3 grid5(kh * q.mt * q.ntile * q.splits);
-#define CUTIE_WG5_LAUNCH_DT(DT_, KW_, MASK_)                                                                      \
+#define CUTIE_WG5_LAUNCH_DT(DT_, KW_, MASK_, NARROW_)                                                             \
     do {                                                                                                          \
-        CUTIE_CHECK_HIP(hipFuncSetAttribute((const void*)wgrad5_kernel<DT_, KW_, MASK_>,                          \
+        CUTIE_CHECK_HIP(hipFuncSetAttribute((const void*)wgrad5_kernel<DT_, KW_, MASK_, NARROW_>,                 \
                                             hipFuncAttributeMaxDynamicSharedMemorySize, WG5_LDS));                \
-        hipLaunchKernelGGL((wgrad5_kernel<DT_, KW_, MASK_>), grid5, dim3(WG5_NT), WG5_LDS, stream, q);            \
+        hipLaunchKernelGGL((wgrad5_kernel<DT_, KW_, MASK_, NARROW_>), grid5, dim3(WG5_NT), WG5_LDS, stream, q);   \
     } while (0)
-#define CUTIE_WG5_LAUNCH(KW_, MASK_)                                                                              \
+#define CUTIE_WG5_LAUNCH(KW_, MASK_, NARROW_)                                                                     \
     do {                                                                                                          \
-        if (dtype == CUTIE_BF16) CUTIE_WG5_LAUNCH_DT(CUTIE_BF16, KW_, MASK_);                                     \
-        else CUTIE_WG5_LAUNCH_DT(CUTIE_F16, KW_, MASK_);                                                          \
+        if (dtype == CUTIE_BF16) CUTIE_WG5_LAUNCH_DT(CUTIE_BF16, KW_, MASK_, NARROW_);                            \
+        else CUTIE_WG5_LAUNCH_DT(CUTIE_F16, KW_, MASK_, NARROW_);                                                 \
     } while (0)
-            if (kw == 5 && mask == 0x3FF) CUTIE_WG5_LAUNCH(5, 0x3FF);
-            else if (kw == 5 && mask == 0x1FE) CUTIE_WG5_LAUNCH(5, 0x1FE);
-            else if (kw == 5) CUTIE_WG5_LAUNCH(5, -1);
-            else if (kw == 3) CUTIE_WG5_LAUNCH(3, -1);
-            else CUTIE_WG5_LAUNCH(1, -1);
+            const bool narrow = cout <= 64;      // one cout tile, half of it (or more) padding
+            if (narrow) {
+                if (kw == 5 && mask == 0x3FF) CUTIE_WG5_LAUNCH(5, 0x3FF, true);
+                else if (kw == 5) CUTIE_WG5_LAUNCH(5, -1, true);
+                else if (kw == 3) CUTIE_WG5_LAUNCH(3, -1, true);
+                else CUTIE_WG5_LAUNCH(1, -1, true);
+            } else if (kw == 5 && mask == 0x3FF) CUTIE_WG5_LAUNCH(5, 0x3FF, false);
+            else if (kw == 5 && mask == 0x1FE) CUTIE_WG5_LAUNCH(5, 0x1FE, false);
+            else if (kw == 5) CUTIE_WG5_LAUNCH(5, -1, false);
+            else if (kw == 3) CUTIE_WG5_LAUNCH(3, -1, false);
+            else CUTIE_WG5_LAUNCH(1, -1, false);
 #undef CUTIE_WG5_LAUNCH
 #undef CUTIE_WG5_LAUNCH_DT
             CUTIE_CHECK_LAUNCH();
