@@ -837,7 +837,7 @@ static int conv_fwd_impl(const cutie_conv_seg* segs, int n_segs, int B, int H, i
         q.TH = th; q.TWB = tcb;
         q.tiles_h = (int)cutie::cdiv(H, th);
         q.tiles_w = (int)cutie::cdiv(W, tcb * 16);
-        q.n_tiles_n = n_out / bn;
+        q.n_tiles_n = (int)cutie::cdiv(n_out, bn);
         if ((long long)B * q.tiles_h * q.tiles_w * q.n_tiles_n < (1ll << 31)) {
             static const bool fuse_on = !(getenv("CUTIE_FUSE_NORM_BWD") && atoi(getenv("CUTIE_FUSE_NORM_BWD")) == 0);
             const bool fuse = nb && fuse_on && nb->a_dtype == dtype && (nb->ld_a * 2) % 16 == 0 && cutie::aligned16(nb->a) &&

@@ -408,7 +408,8 @@ __global__ __launch_bounds__(CW_NT) void conv_wide_kernel(ConvParams p) {
 
 }  // namespace
 
-// channel tile for n_out: 256 where it divides, else 128, else 64; 0 = not a wide-kernel shape
+// channel tile for n_out: 256 where it divides, else 128, else 64 (also for n_out < 64 in whole 16-byte pieces);
+// 0 = not a wide-kernel shape
 int conv_wide_tile(const ConvParams& p) {
     if ((p.ld_out * 2) % 16 != 0 || !aligned16(p.out) || p.relu == 2) return 0;    // sigmoid: generic kernel only
     for (int s = 0; s < p.nseg; ++s)
@@ -416,6 +417,9 @@ int conv_wide_tile(const ConvParams& p) {
     if (p.n_out % 256 == 0) return 256;
     if (p.n_out % 128 == 0) return 128;
     if (p.n_out % 64 == 0) return 64;
+    // a narrow layer (CUTIE2's 32-channel image branch): one 64-channel tile, the rows and columns beyond n_out are
+    // zero weight rows and masked stores - half the tile idles, where the general kernel pads to 128 channels
+    if (p.n_out < 64 && p.n_out % 8 == 0) return 64;
     return 0;
 }
 

@@ -284,6 +284,10 @@ WIDE_CASES = [
     (8, 64, 64, 64, 256, 3, 5, 16),
     (8, 32, 64, 64, 128, 3, 5, 8),
     (16, 20, 40, 64, 64, 3, 3, 4),
+    # fewer than 64 output channels: one 64-channel tile with masked rows / stores (CUTIE2's image branch)
+    (2, 40, 64, 64, 32, 3, 3, 2),
+    (1, 33, 50, 64, 48, 3, 5, 1),
+    (8, 16, 64, 64, 8, 3, 3, 1),
 ]
 
 
@@ -352,7 +356,8 @@ DGRAD_STATS_CASES = [
     (2, 32, 64, 64, 128, 2),       # channel tile 128 (two workgroups per pixel tile)
     (1, 40, 64, 128, 64, 16),      # channel tile 64
     (1, 7, 80, 64, 512, 2),        # two channel tiles of 256, tiles wider than tall
-    (2, 12, 64, 64, 32, 1),        # not a wide-kernel shape: conv + the separate reduction behind the same entry point
+    (2, 12, 64, 64, 32, 1),        # fewer than 64 channels: masked 64-channel tile
+    (2, 12, 64, 64, 36, 1),        # not a wide-kernel shape: conv + the separate reduction behind the same entry point
     (8, 64, 64, 64, 256, 16),      # heaviest-first tile order: slots are still indexed by the tile, not by the block
 ]
 
@@ -368,7 +373,7 @@ def test_conv_dgrad_in_stats(ops, dt, case):
     w = (torch.randn((3, 5, C, cz), generator=g) * 0.05).to(tdt).float()     # forward weights C -> cz
     dz = _rand_act(g, (B, H, W, cz), tdt).to(DEV)
     a = torch.relu(torch.randn((B, H, W, C), generator=g) + 0.2).to(tdt)
-    ld = C + 8
+    ld = (C + 15) // 8 * 8
     ad = torch.zeros((B, H, W, ld), dtype=tdt, device=DEV)
     ad[..., :C] = a.to(DEV)
     T = ops.conv_stats_tiles(H, W)
