@@ -446,7 +446,8 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradParams p) {
 constexpr int WG5_NT = 512;
 constexpr int WG5_KW = 5;      // at most 5 column taps
 constexpr int WG5_PIX = 64;    // pixels of K per stage
-constexpr int WG5_XROWS = 96;  // staged patch rows (24 pieces): 64 + 2 * pad <= 96
+constexpr int WG5_XROWS = 96;  // staged patch rows (24 pieces): 64 + 2 * pad <= 96 ...
+constexpr int WG5_XROWS_WIDE = 128;   // ... or 32 pieces = the whole patch buffer (WIDEPATCH instances)
 // LDS map: x patch 0 at 0, x patch 1 at 32 KB, dz rows at 64 KB and 80 KB (the halves toggle by XOR)
 constexpr int WG5_XSTRIDE = 32768, WG5_D0 = 65536, WG5_DBUF = WG5_PIX * 256;
 constexpr int WG5_LDS = WG5_D0 + 2 * WG5_DBUF;
@@ -462,14 +463,16 @@ struct Wgrad5Params {
 
 //   NARROW (cout <= 64, one cout tile): the eight waves are 8 (cin) x 1 (cout) instead of 4 x 2 - a wave owns
 //   16 cin x 64 cout - so that no wave multiplies the padding half of a 128-wide cout tile.
-template <int DT, int KW, int MASK, bool NARROW = false>
+//   WIDEPATCH: a patch of up to 128 rows (64 + 2 x 32 halo: dilation 16 on an image wider than one 64-pixel
+//   segment) - a fourth x piece per wave fills the 32 KB a patch buffer has.
+template <int DT, int KW, int MASK, bool NARROW = false, bool WIDEPATCH = false>
 __global__ __launch_bounds__(WG5_NT, 2) void wgrad5_kernel(Wgrad5Params p) {
     constexpr int ES = 2;
     constexpr int MBLK = NARROW ? 1 : 2;     // 16-channel cin blocks per wave
     constexpr int ROWB = 256;       // bytes per staged pixel row: 128 channels
     constexpr bool TWO = KW == 1;   // two cin tiles per workgroup in place of taps
     constexpr int NT_ = TWO ? 2 : KW;        // accumulator sets: taps, or cin tiles
-    constexpr int NX = TWO ? 4 : 3;          // x pieces per wave and row
+    constexpr int NX = (TWO || WIDEPATCH) ? 4 : 3;   // x pieces per wave and row
     constexpr int NPC = NX + 2;              // + the two dz pieces
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int pwx = WG5_PIX + 2 * p.pad;                    // patch rows that hold data
@@ -949,7 +952,8 @@ extern "C" int cutie_conv_wgrad(const void* x, int ld_x, int cin, const void* dz
         }
         q.pad = pad;
         const int pwx = WG5_PIX + 2 * pad;
-        if (pwx <= WG5_XROWS && (kw == 1 || kw == 3 || kw == 5)) {
+        const bool widepatch = pwx > WG5_XROWS;
+        if ((pwx <= WG5_XROWS || (pwx <= WG5_XROWS_WIDE && kw == 5 && cout > 64)) && (kw == 1 || kw == 3 || kw == 5)) {
             // liveness pattern of the (K block, tap) pairs when a row is one 64-pixel segment
             int mask = -1;
             if (q.nwseg == 1 && kw == 5 && W > 32) {
@@ -973,7 +977,17 @@ extern "C" int cutie_conv_wgrad(const void* x, int ld_x, int cin, const void* dz
         else CUTIE_WG5_LAUNCH_DT(CUTIE_F16, KW_, MASK_, NARROW_);                                                 \
     } while (0)
             const bool narrow = cout <= 64;      // one cout tile, half of it (or more) padding
-            if (narrow) {
+            if (widepatch) {
+                if (dtype == CUTIE_BF16) {
+                    CUTIE_CHECK_HIP(hipFuncSetAttribute((const void*)wgrad5_kernel<CUTIE_BF16, 5, -1, false, true>,
+                                                        hipFuncAttributeMaxDynamicSharedMemorySize, WG5_LDS));
+                    hipLaunchKernelGGL((wgrad5_kernel<CUTIE_BF16, 5, -1, false, true>), grid5, dim3(WG5_NT), WG5_LDS, stream, q);
+                } else {
+                    CUTIE_CHECK_HIP(hipFuncSetAttribute((const void*)wgrad5_kernel<CUTIE_F16, 5, -1, false, true>,
+                                                        hipFuncAttributeMaxDynamicSharedMemorySize, WG5_LDS));
+                    hipLaunchKernelGGL((wgrad5_kernel<CUTIE_F16, 5, -1, false, true>), grid5, dim3(WG5_NT), WG5_LDS, stream, q);
+                }
+            } else if (narrow) {
                 if (kw == 5 && mask == 0x3FF) CUTIE_WG5_LAUNCH(5, 0x3FF, true);
                 else if (kw == 5) CUTIE_WG5_LAUNCH(5, -1, true);
                 else if (kw == 3) CUTIE_WG5_LAUNCH(3, -1, true);

@@ -443,6 +443,9 @@ WGRAD_CASES = [
     (1, 5, 130, 64, 64, 3, 3, 4),
     (8, 64, 64, 128, 128, 3, 5, 16),    # many rows per workgroup: both LDS halves, dead (K block, tap) pairs
     (8, 64, 64, 128, 128, 3, 5, 8),
+    # dilation 16 on an image wider than one 64-pixel segment: 128-row patch (64 + 2 x 32 halo)
+    (2, 8, 128, 64, 128, 3, 5, 16),
+    (1, 6, 100, 128, 128, 3, 5, 16),
     # 1x1 layers: two cin tiles per workgroup (ragged second tile, several tile pairs, one tile only)
     (2, 16, 64, 320, 128, 1, 1, 1),
     (1, 8, 64, 1024, 256, 1, 1, 1),

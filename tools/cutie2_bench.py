@@ -62,10 +62,13 @@ if __name__ == "__main__":
     ap.add_argument("--dtype", default="bf16")
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=12)
-    ap.add_argument("--only", default="", help="'aspp32': config 4 at B = 32 alone (for a profiler)")
+    ap.add_argument("--only", default="", help="'aspp32': config 4 at B = 32 alone, 'dilate8': config 5 training at B = 8 alone (for a profiler)")
     a = ap.parse_args()
     if a.only == "aspp32":
         run("aspp", 32, 128, 64, 28790, 9, a.dtype, "infer", a.steps, a.warmup)
+        sys.exit(0)
+    if a.only == "dilate8":
+        run("dilate", 8, 256, 128, 28790, 9, a.dtype, "train", a.steps, a.warmup)
         sys.exit(0)
     for B in (32, 128, 512):
         run("aspp", B, 128, 64, 28790, 9, a.dtype, "infer", a.steps, a.warmup)
