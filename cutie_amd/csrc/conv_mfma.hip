@@ -963,6 +963,11 @@ extern "C" int cutie_conv_wgrad(const void* x, int ld_x, int cin, const void* dz
                         const int px0 = ks * 32, sx = (t - kw / 2) * dil;
                         if (!(px0 + sx + 31 < 0 || px0 + sx >= W)) mask |= 1 << (ks * kw + t);
                     }
+            } else if (q.nwseg > 1 && kw == 5 && 2 * dil <= 31) {
+                // several segments per row, every shift shorter than a K block: no (K block, tap) pair is ever wholly
+                // outside on the left, and what lies beyond the right edge is staged as zeros - the all-live pattern
+                // (compile-time, so the row loop pipelines) is exact
+                mask = 0x3FF;
             }
             const dim3 grid5(kh * q.mt * q.ntile * q.splits);
 #define CUTIE_WG5_LAUNCH_DT(DT_, KW_, MASK_, NARROW_)                                                             \

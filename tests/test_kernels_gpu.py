@@ -443,6 +443,10 @@ WGRAD_CASES = [
     (1, 5, 130, 64, 64, 3, 3, 4),
     (8, 64, 64, 128, 128, 3, 5, 16),    # many rows per workgroup: both LDS halves, dead (K block, tap) pairs
     (8, 64, 64, 128, 128, 3, 5, 8),
+    # several 64-pixel segments per row with short shifts: the all-live compile-time pattern (also on a ragged last segment)
+    (1, 6, 128, 64, 128, 3, 5, 8),
+    (2, 5, 100, 64, 128, 3, 5, 2),
+    (1, 4, 70, 64, 128, 3, 5, 1),
     # dilation 16 on an image wider than one 64-pixel segment: 128-row patch (64 + 2 x 32 halo)
     (2, 8, 128, 64, 128, 3, 5, 16),
     (1, 6, 100, 128, 128, 3, 5, 16),
