@@ -6,6 +6,7 @@ an entry point fails, a CutieError is raised.
 """
 import ctypes
 import os
+import threading
 
 import torch
 
@@ -114,8 +115,18 @@ def _check(rc, name):
         raise CutieError("%s failed (%d): %s" % (name, rc, msg.decode() if msg else "?"))
 
 
-def stream():
-    return torch.cuda.current_stream().cuda_stream
+_tls = threading.local()      # .dev: device of the tensor most recently handed to ptr() on this thread
+
+
+def stream(device=None):
+    """The HIP stream a call's kernels go to: torch's current stream OF THE DEVICE THAT OWNS THE CALL'S TENSORS (the
+    device of the last tensor given to ptr() on this thread - every binding evaluates its ptr() arguments before its
+    trailing stream()), not of whatever device happens to be current on the calling thread.  `device` overrides, for
+    calls whose pointers sit inside a descriptor array."""
+    if device is not None:
+        _tls.dev = torch.device(device)
+    dev = getattr(_tls, "dev", None)
+    return torch.cuda.current_stream(dev).cuda_stream
 
 
 def dt_of(t):
@@ -149,6 +160,7 @@ def ptr(t):
         return None
     if not t.is_cuda:
         raise CutieError("expected a device tensor")
+    _tls.dev = t.device
     return t.data_ptr()
 
 
@@ -165,4 +177,13 @@ def ld_of(t):
 
 
 def call(name, *args):
-    _check(getattr(lib(), name)(*args), name)
+    """Runs an entry point with the device of its tensors current (per-device library state - dynamic-LDS grants,
+    the static work area of cutie_hnm_weights_static - belongs to the CURRENT device)."""
+    fn = getattr(lib(), name)
+    dev = getattr(_tls, "dev", None)
+    if dev is not None and dev.index is not None and dev.index != torch.cuda.current_device():
+        with torch.cuda.device(dev):
+            rc = fn(*args)
+    else:
+        rc = fn(*args)
+    _check(rc, name)

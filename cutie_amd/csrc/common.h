@@ -11,6 +11,17 @@ namespace cutie {
 
 void set_error(const char* fmt, ...);
 
+// environment switches of the A/B scripts, read once at library load (core.hip)
+struct Config {
+    bool conv_wide;       // CUTIE_CONV_WIDE=0: every conv on the general kernel
+    bool fuse_norm_bwd;   // CUTIE_FUSE_NORM_BWD=0: data gradient and norm-backward sums as two passes
+    bool conv_lpt;        // CUTIE_CONV_LPT=0: conv_wide tiles in row-major order
+};
+const Config& config();
+
+// grants `bytes` of dynamic LDS to a kernel on the current device, once (core.hip); returns CUTIE_OK / CUTIE_E_HIP
+int ensure_dyn_lds(const void* fn, int bytes);
+
 #define CUTIE_CHECK_ARG(cond, ...)                     \
     do {                                               \
         if (!(cond)) {                                 \
@@ -30,6 +41,11 @@ void set_error(const char* fmt, ...);
     } while (0)
 
 #define CUTIE_CHECK_LAUNCH() CUTIE_CHECK_HIP(hipGetLastError())
+
+#define CUTIE_ENSURE_LDS(kernel, bytes)                                                   \
+    do {                                                                                  \
+        if (int e__ = cutie::ensure_dyn_lds((const void*)(kernel), (int)(bytes))) return e__; \
+    } while (0)
 
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 static inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }

@@ -723,7 +723,7 @@ inline int wgrad_splits(int B, int H, int cin, int cout, int taps) {
 template <int DT, int ODT>
 int launch_conv(const ConvParams& p, size_t lds, hipStream_t stream) {
     const void* fn = (const void*)conv_kernel<DT, ODT>;
-    if (lds > 64 * 1024) CUTIE_CHECK_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    if (lds > 64 * 1024) CUTIE_ENSURE_LDS(fn, lds);
     const long long grid = (long long)p.B * p.tiles_h * p.tiles_w * p.n_tiles_n;
     hipLaunchKernelGGL((conv_kernel<DT, ODT>), dim3((unsigned)grid), dim3(CONV_NT), lds, stream, p);
     CUTIE_CHECK_LAUNCH();
@@ -831,7 +831,7 @@ static int conv_fwd_impl(const cutie_conv_seg* segs, int n_segs, int B, int H, i
                     segs[0].dil, W);
     CUTIE_CHECK_ARG((long long)B * p.tiles_h * p.tiles_w * p.n_tiles_n < (1ll << 31), "conv_fwd: grid too large");
     // wide layers: 256-pixel x 256-channel tiles fed by LDS-DMA (conv_wide.hip)
-    static const bool wide_on = !(getenv("CUTIE_CONV_WIDE") && atoi(getenv("CUTIE_CONV_WIDE")) == 0);
+    const bool wide_on = cutie::config().conv_wide;
     const int bn = (wide_on && dtype != CUTIE_F32 && out_dtype == dtype) ? cutie::conv_wide_tile(p) : 0;
     if (bn) {
         ConvParams q = p;
@@ -842,7 +842,7 @@ static int conv_fwd_impl(const cutie_conv_seg* segs, int n_segs, int B, int H, i
         q.tiles_w = (int)cutie::cdiv(W, tcb * 16);
         q.n_tiles_n = (int)cutie::cdiv(n_out, bn);
         if ((long long)B * q.tiles_h * q.tiles_w * q.n_tiles_n < (1ll << 31)) {
-            static const bool fuse_on = !(getenv("CUTIE_FUSE_NORM_BWD") && atoi(getenv("CUTIE_FUSE_NORM_BWD")) == 0);
+            const bool fuse_on = cutie::config().fuse_norm_bwd;
             const bool fuse = nb && fuse_on && nb->a_dtype == dtype && (nb->ld_a * 2) % 16 == 0 && cutie::aligned16(nb->a) &&
                               q.tiles_h * q.tiles_w <= nb->red_tiles;
             if (fuse) {
@@ -972,8 +972,7 @@ extern "C" int cutie_conv_wgrad(const void* x, int ld_x, int cin, const void* dz
             const dim3 grid5(kh * q.mt * q.ntile * q.splits);
 #define CUTIE_WG5_LAUNCH_DT(DT_, KW_, MASK_, NARROW_)                                                             \
     do {                                                                                                          \
-        CUTIE_CHECK_HIP(hipFuncSetAttribute((const void*)wgrad5_kernel<DT_, KW_, MASK_, NARROW_>,                 \
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, WG5_LDS));                \
+        CUTIE_ENSURE_LDS((wgrad5_kernel<DT_, KW_, MASK_, NARROW_>), WG5_LDS);                                     \
         hipLaunchKernelGGL((wgrad5_kernel<DT_, KW_, MASK_, NARROW_>), grid5, dim3(WG5_NT), WG5_LDS, stream, q);   \
     } while (0)
 #define CUTIE_WG5_LAUNCH(KW_, MASK_, NARROW_)                                                                     \
@@ -984,12 +983,10 @@ extern "C" int cutie_conv_wgrad(const void* x, int ld_x, int cin, const void* dz
             const bool narrow = cout <= 64;      // one cout tile, half of it (or more) padding
             if (widepatch) {
                 if (dtype == CUTIE_BF16) {
-                    CUTIE_CHECK_HIP(hipFuncSetAttribute((const void*)wgrad5_kernel<CUTIE_BF16, 5, -1, false, true>,
-                                                        hipFuncAttributeMaxDynamicSharedMemorySize, WG5_LDS));
+                    CUTIE_ENSURE_LDS((wgrad5_kernel<CUTIE_BF16, 5, -1, false, true>), WG5_LDS);
                     hipLaunchKernelGGL((wgrad5_kernel<CUTIE_BF16, 5, -1, false, true>), grid5, dim3(WG5_NT), WG5_LDS, stream, q);
                 } else {
-                    CUTIE_CHECK_HIP(hipFuncSetAttribute((const void*)wgrad5_kernel<CUTIE_F16, 5, -1, false, true>,
-                                                        hipFuncAttributeMaxDynamicSharedMemorySize, WG5_LDS));
+                    CUTIE_ENSURE_LDS((wgrad5_kernel<CUTIE_F16, 5, -1, false, true>), WG5_LDS);
                     hipLaunchKernelGGL((wgrad5_kernel<CUTIE_F16, 5, -1, false, true>), grid5, dim3(WG5_NT), WG5_LDS, stream, q);
                 }
             } else if (narrow) {

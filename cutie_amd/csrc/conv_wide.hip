@@ -21,7 +21,6 @@
 //     data gradient into an instance-normalised layer - that layer's backward sums (sum dy, sum dy * xhat)
 //     taken in the same store pass (ConvParams::bw_*), so no separate reduction pass reads dy and a again.
 #include "conv_common.h"
-#include <stdlib.h>
 
 namespace cutie {
 namespace {
@@ -426,8 +425,7 @@ int conv_wide_tile(const ConvParams& p) {
 template <int DT, int BN>
 static int launch_one(const ConvParams& p, hipStream_t stream) {
     const long long grid = (long long)p.B * p.tiles_h * p.tiles_w * p.n_tiles_n;
-    CUTIE_CHECK_HIP(hipFuncSetAttribute((const void*)conv_wide_kernel<DT, BN>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                        Shape<BN>::LDS));
+    CUTIE_ENSURE_LDS((conv_wide_kernel<DT, BN>), Shape<BN>::LDS);
     hipLaunchKernelGGL((conv_wide_kernel<DT, BN>), dim3((unsigned)grid), dim3(CW_NT), Shape<BN>::LDS, stream, p);
     CUTIE_CHECK_LAUNCH();
     return CUTIE_OK;
@@ -437,7 +435,7 @@ static int launch_one(const ConvParams& p, hipStream_t stream) {
 // a dilated layer differ up to 2x between the centre and the corners of the image.  Dispatch is in block order, so
 // putting the heavy tiles first lets the light ones even out the end of the launch.
 static void plan_tile_order(ConvParams& p) {
-    static const bool on = !(getenv("CUTIE_CONV_LPT") && atoi(getenv("CUTIE_CONV_LPT")) == 0);
+    const bool on = config().conv_lpt;
     p.perm_n = 0;
     const int nt = p.tiles_h * p.tiles_w;
     if (!on || nt < 2 || nt > CONV_MAX_PERM || (p.B & 7) != 0) return;

@@ -1,10 +1,44 @@
 // Error plumbing and version of the C ABI (include/cutie_hip.h).
 #include "common.h"
 
+#include <stdlib.h>
+
+#include <mutex>
 #include <string>
+#include <vector>
 
 namespace cutie {
 static thread_local std::string g_last_error;
+
+// A/B switches of the measurement scripts, read ONCE when the library is loaded (never per call)
+static bool env_on(const char* name) {
+    const char* v = getenv(name);
+    return !(v && atoi(v) == 0);
+}
+static const Config g_config = {env_on("CUTIE_CONV_WIDE"), env_on("CUTIE_FUSE_NORM_BWD"), env_on("CUTIE_CONV_LPT")};
+const Config& config() { return g_config; }
+
+// hipFuncAttributeMaxDynamicSharedMemorySize is a property of (kernel, device): set when a kernel first needs more
+// than it has been granted there, not on every launch.  The table is a cache of what the runtime already holds.
+int ensure_dyn_lds(const void* fn, int bytes) {
+    struct Entry { const void* fn; int dev, bytes; };
+    static std::mutex mu;
+    static std::vector<Entry> granted;
+    int dev = 0;
+    CUTIE_CHECK_HIP(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lock(mu);
+    for (Entry& e : granted) {
+        if (e.fn == fn && e.dev == dev) {
+            if (e.bytes >= bytes) return CUTIE_OK;
+            CUTIE_CHECK_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+            e.bytes = bytes;
+            return CUTIE_OK;
+        }
+    }
+    CUTIE_CHECK_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    granted.push_back({fn, dev, bytes});
+    return CUTIE_OK;
+}
 
 void set_error(const char* fmt, ...) {
     char buf[1024];

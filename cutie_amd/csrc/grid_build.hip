@@ -306,8 +306,7 @@ extern "C" int cutie_grid_build(const int32_t* tok_box, const int32_t* tok_id, c
     if (cap > 2048) cap = 2048;
     a.cap = (int)cap;
     const size_t lds_total = grid_part + cap * 48;
-    CUTIE_CHECK_HIP(hipFuncSetAttribute((const void*)grid_build_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                        (int)lds_total));
+    CUTIE_ENSURE_LDS(grid_build_kernel, lds_total);
     hipLaunchKernelGGL(grid_build_kernel, dim3(n_docs), dim3(GB_NT), lds_total, stream, a);
     CUTIE_CHECK_LAUNCH();
     return CUTIE_OK;

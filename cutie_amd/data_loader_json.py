@@ -61,17 +61,21 @@ def _opt(params, name, default):
 
 
 class _Prefetcher(object):
-    def __init__(self, fn, depth):
+    def __init__(self, fn, depth, device=None):
         import queue
         import threading
         self._q = queue.Queue(maxsize=max(1, int(depth)))
         self._stop = threading.Event()
         self._fn = fn
+        self._device = device      # the creating thread's GPU: a new thread starts with device 0 current
         self._t = threading.Thread(target=self._run, name='cutie-prefetch', daemon=True)
         self._t.start()
 
     def _run(self):
         import queue
+        if self._device is not None:
+            import torch
+            torch.cuda.set_device(self._device)
         while not self._stop.is_set():
             try:
                 item = ('ok', self._fn())
@@ -116,6 +120,8 @@ class DataLoader(object):
         self.encoding_factor = 1
         self.classes = list(_opt(params, 'classes', DEFAULT_CLASSES))
         self.device = device          # torch device of the grid builder; None = current GPU
+        import threading
+        self._tls = threading.local()     # .last_device: per thread, so a prefetch thread and a foreground fetch_* do not clobber each other
         self.verbose = verbose
 
         self.doc_path = params.doc_path
@@ -245,7 +251,7 @@ class DataLoader(object):
                  'data_image': np.array(images), 'ps_1d_indices': np.array(ps_1d_indices),
                  'bboxes': bboxes, 'label_mapids': label_mapids, 'bbox_mapids': bbox_mapids,
                  'file_name': file_names, 'shape': [rows, cols]}
-        batch['device'] = self._last_device       # {'grid_table': int32 [B,H,W,1], 'gt_classes': int8 [B,H,W]}
+        batch['device'] = self._tls.last_device       # {'grid_table': int32 [B,H,W,1], 'gt_classes': int8 [B,H,W]}
         return batch
 
     def next_batch(self):
@@ -278,7 +284,10 @@ class DataLoader(object):
         that the host half of a batch (shape choice, packing, the read-back the evaluation dicts need)
         overlaps the device step instead of serialising with it as main_train_json.py:228 does.
         Batches come out in the order the thread drew them; call .close() (or exhaust it) to stop."""
-        return _Prefetcher(getattr(self, fetch), depth)
+        import torch
+        dev = torch.device(self.device) if self.device is not None else (
+            torch.device('cuda', torch.cuda.current_device()) if torch.cuda.is_available() else None)
+        return _Prefetcher(getattr(self, fetch), depth, dev)
 
     def fetch_validation_data(self):
         """:210-272 (one document; the reference takes max(rows_target, .) for both axes, :223-224)"""
@@ -426,7 +435,7 @@ class DataLoader(object):
         ps_y = res['ps_y'].cpu().numpy()
         order = res['order'].cpu().numpy()
         place = res['place'].cpu().numpy()
-        self._last_device = {'grid_table': res['grid'].unsqueeze(-1), 'gt_classes': res['labels'],
+        self._tls.last_device = {'grid_table': res['grid'].unsqueeze(-1), 'gt_classes': res['labels'],
                              'ps_indices_x': res['ps_x'], 'ps_indices_y': res['ps_y']}
 
         grid_tables, grid_labels, ps_indices_x, ps_indices_y = [], [], [], []

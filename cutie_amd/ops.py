@@ -101,13 +101,13 @@ def pack_weights_batched(entries, dt):
             arr[i].cin_pad = wf.shape[2] if wf is not None else 0
             arr[i].cout_pad = wd.shape[2] if wd is not None else 0
         batches.append(arr)
-    replay_pack(batches, dt)
+    replay_pack(batches, dt, entries[0][0].device)
     return batches
 
 
-def replay_pack(batches, dt):
+def replay_pack(batches, dt, device):
     for arr in batches:
-        call("cutie_pack_weights_batched", arr, len(arr), dt, stream())
+        call("cutie_pack_weights_batched", arr, len(arr), dt, stream(device))
 
 
 def sum_rows_batched(entries, B, accumulate=False):
@@ -121,13 +121,13 @@ def sum_rows_batched(entries, B, accumulate=False):
                 raise capi.CutieError("sum_rows_batched: entry %d shapes %s -> %s" % (i, tuple(part.shape), tuple(out.shape)))
             arr[i].part, arr[i].out, arr[i].C = ptr(part), ptr(out), out.numel()
         batches.append(arr)
-    replay_sum_rows(batches, B, accumulate)
+    replay_sum_rows(batches, B, entries[0][0].device, accumulate)
     return batches
 
 
-def replay_sum_rows(batches, B, accumulate=False):
+def replay_sum_rows(batches, B, device, accumulate=False):
     for arr in batches:
-        call("cutie_sum_rows_batched", arr, len(arr), B, 1 if accumulate else 0, stream())
+        call("cutie_sum_rows_batched", arr, len(arr), B, 1 if accumulate else 0, stream(device))
 
 
 ACTIVATION_CODE = {None: 0, False: 0, "none": 0, True: 1, "relu": 1, "sigmoid": 2}

@@ -37,10 +37,11 @@ class _Plan(object):
 
 
 class Engine(object):
-    def __init__(self, network, device="cuda:0", dtype="bf16", seed=0, loss_scale=None, overlap_wgrad=None):
-        """dtype: 'bf16' (the headline path), 'f16' (same MFMA rate, 8x finer rounding; backward runs
-        under a dynamic loss scale kept on the device, initial value `loss_scale`, default 4096) or
-        'f32' (parity mode)."""
+    def __init__(self, network, device="cuda:0", dtype="f16", seed=0, loss_scale=None, overlap_wgrad=None):
+        """dtype: 'f16' (the headline path: IEEE half activations and MFMA operands, f32 accumulation, statistics
+        and parameters; meets the 2e-2 logit tolerance; backward runs under a dynamic loss scale kept on the device,
+        initial value `loss_scale`, default 4096), 'bf16' (same tiles and MFMA rate, 8 significant bits: outside the
+        tolerance on deep stacks, kept as an option) or 'f32' (parity mode, 1e-4)."""
         capi.lib()   # fail loudly, before anything else, when the HIP library is absent
         if not torch.cuda.is_available():
             raise CutieError("cutie_amd needs a HIP device (torch.cuda.is_available() is False); there is no CPU path")
@@ -135,7 +136,7 @@ class Engine(object):
             self._pack_batches = ops.pack_weights_batched(
                 [(self.params[n], self.w_fwd[n], self.w_dg[n]) for n in self.conv_w_names], self.dt)
         else:
-            ops.replay_pack(self._pack_batches, self.dt)
+            ops.replay_pack(self._pack_batches, self.dt, self.dev)
 
     # ------------------------------------------------------------------ planning
     def _plan(self, B, H, W, Hi):
@@ -481,7 +482,7 @@ class Engine(object):
             P._sum_rows_batches = [(rows, ops.sum_rows_batched(ents, rows)) for rows, ents in groups.items()]
         else:
             for rows, batches in P._sum_rows_batches:
-                ops.replay_sum_rows(batches, rows)
+                ops.replay_sum_rows(batches, rows, self.dev)
         P.reg_div = 1.0
         P.l2_pending = on_ready is not None
         if on_ready is None:

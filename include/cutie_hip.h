@@ -112,7 +112,8 @@ int cutie_embed_bwd(const int32_t* ids, int64_t n_cells, const void* dout, int l
  * stats (nullable) f32 [B][stats_tiles][n_out][2]: per 256-pixel tile, the sum and sum of squares
  * of the values stored - the instance-norm moments of model_framework.py:423 as partial sums.
  * Tile t of a sample STORES slot t (no float atomics: reruns are bit-identical); slots the launch
- * does not own are left alone, so the caller zeroes the array once per forward pass.  stats_tiles
+ * does not own are left alone, so the caller zeroes the array ONCE, when it allocates it (every later
+ * launch of the same shape stores the same slots again).  stats_tiles
  * >= cutie_conv_stats_tiles(H, W).  The consumers below add the slots in slot order.
  */
 int cutie_conv_stats_tiles(int H, int W);
@@ -141,7 +142,8 @@ int cutie_conv_fwd(const cutie_conv_seg* segs /* host */, int n_segs,
  * store pass of the epilogue from the rounded dy (tile t of a sample STORES slot t; slots the launch does
  * not own are left alone - zero `red` once when it is allocated); otherwise the conv is followed by
  * cutie_in_bwd_stats over all red_tiles slots.  red_tiles >= cutie_conv_stats_tiles(H, W).
- * CUTIE_FUSE_NORM_BWD=0 in the environment selects the two-pass form (A/B measurements). */
+ * CUTIE_FUSE_NORM_BWD=0 in the environment WHEN THE LIBRARY IS LOADED selects the two-pass form (A/B
+ * measurements; the library reads its three CUTIE_* switches once at load, never per call). */
 int cutie_conv_dgrad_in_stats(const cutie_conv_seg* segs /* host */, int n_segs,
                               int B, int H, int W, int n_out,
                               void* out, int ld_out, int out_dtype,
@@ -240,7 +242,9 @@ int cutie_spatial_mean_bcast(const void* x, int ld_x, int x_dtype, void* out, in
  *         background ce (ties: lower index first, as tf.nn.top_k); weight[n] = 1/Nfg (fg),
  *         1/num_bg (selected bg), 0 otherwise;  loss_out[0] = mean(fg ce) + mean(selected)
  *         (NaN when either set is empty, as reduce_mean of an empty tensor), loss_out[1] =
- *         Nfg, loss_out[2] = num_bg.  Single workgroup; workspace >= hnm_workspace_bytes.
+ *         Nfg, loss_out[2] = num_bg.  A three-level radix select (11 + 11 + 10 bits of the CE key) over a
+ *         wide grid of workgroups, whose histograms and counters live in the workspace
+ *         (>= cutie_hnm_workspace_bytes(n_cells), 16-byte aligned, clobbered; no pre-fill needed).
  * bwd:    dlogits[n,c] = weight[n] * (probs[n,c] - [c == label[n]])
  */
 int cutie_softmax_ce_fwd(const void* logits, int ld, int dtype, const int32_t* labels,

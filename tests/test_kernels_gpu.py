@@ -679,7 +679,7 @@ def test_batched_pack_and_sum_rows_match_single(ops, dt):
         assert wf2 is None or torch.equal(wf2, wf)
         assert wd2 is None or torch.equal(wd2, wd)
     ws[0].mul_(2.0)                                                   # replay reads the current weights
-    ops.replay_pack(batches, dt)
+    ops.replay_pack(batches, dt, DEV)
     assert torch.equal(entries[0][1], ops.pack_weights(ws[0], dt)[0])
 
     B = 5

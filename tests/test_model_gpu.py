@@ -3,13 +3,13 @@ every named layer of CUTIE-ASPP, logits, softmax, argmax agreement, the three lo
 gradient tf.gradients would produce, the TF-style global norm and one clipped Adam step.
 
 Tolerances (BASELINE.json north_star): f32 path - every layer and the logits within 1e-4,
-measured as max |got - ref| / max |ref| (the strictest reading).  bf16 path - the 2e-2 target is
-NOT met on this seeded random-initialised network and the test says so: bf16 operands put
-~5e-3 relative L2 error on every layer's normalised output (instance norm re-scales each
-channel to unit variance, so nothing is attenuated) and fourteen layers compound it to ~3.8e-2
-relative L2 / ~3.4e-2 max-norm on the logits.  The bound asserted here is the measured level
-with margin (rel-L2 < 6e-2, max-norm < 8e-2) so that regressions show; DESIGN.md lists the
-levers (f32 pre-norm activations, normalise-on-load) under "next".  Per-cell argmax agreement >= 99.9 % on the cells
+measured as max |got - ref| / max |ref| (the strictest reading).  f16 path - the HEADLINE 16-bit path
+(Engine's and bench.py's default): every layer and the logits within north_star's 16-bit bound 2e-2 in
+both rel-L2 and max-norm, every gradient within 3e-2 rel-L2.  bf16 is a non-default option of the same
+kernels: its 8-bit significand puts ~5e-3 relative L2 error on every layer's normalised output (instance
+norm re-scales each channel to unit variance, so nothing is attenuated) and fourteen layers compound it to
+~3.8e-2 on the logits - OUTSIDE the tolerance, which is why it is not the headline; its bound here is the
+measured level with margin so that regressions show.  Per-cell argmax agreement >= 99.9 % on the cells
 whose oracle top-2 margin exceeds the path's logit tolerance (the share of such cells and the
 agreement over ALL cells are printed; the f32 path must reach 99.9 % over all cells).
 The oracle is PARITY UNPINNED against TensorFlow (see its header); the aspp_4 slice is
@@ -61,7 +61,12 @@ def oracle_run():
     return dict(B=B, H=H, W=W, grid=grid, labels=labels, params=params, out=out)
 
 
-@pytest.mark.parametrize("dtype", ["f32", "bf16", "f16"])
+HEADLINE_TOL = 2e-2          # north_star's 16-bit logit tolerance; the f16 path must meet it everywhere
+BF16_OPTION_TOL = 6e-2       # the non-default bf16 option: measured 3.8e-2 (14 layers) with margin, NOT a parity claim
+BF16_OPTION_TOL_DEEP = 1.5e-1   # the same over CUTIE2's 21 / 26 layers (measured 1.1e-1)
+
+
+@pytest.mark.parametrize("dtype", ["f32", "f16", "bf16"])
 def test_cutie_aspp_forward_backward_parity(oracle_run, dtype):
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
@@ -69,7 +74,7 @@ def test_cutie_aspp_forward_backward_parity(oracle_run, dtype):
     from cutie_amd.runtime import Engine
     from cutie_amd.train import Trainer
     r = oracle_run
-    tol = {"f32": 1e-4, "bf16": 6e-2, "f16": 2e-2}[dtype]
+    tol = {"f32": 1e-4, "f16": HEADLINE_TOL, "bf16": BF16_OPTION_TOL}[dtype]
     net = CUTIERes(V, C, params_ns())
     fetches = net.build_loss()
     assert [f.name for f in fetches] == ["model_loss", "regularization_loss", "total_loss", "cls_logits", "softmax"]
@@ -90,9 +95,9 @@ def test_cutie_aspp_forward_backward_parity(oracle_run, dtype):
         if dtype == "f32":
             assert e < tol, (name, e)
         elif dtype == "f16":      # the north-star 16-bit bound, in both norms
-            assert report2[name] < 2e-2 and e < 2e-2, (name, report2[name], e)
+            assert report2[name] < HEADLINE_TOL and e < HEADLINE_TOL, (name, report2[name], e)
         else:
-            assert report2[name] < 6e-2 and e < 8e-2, (name, report2[name], e)
+            assert report2[name] < BF16_OPTION_TOL and e < 8e-2, (name, report2[name], e)
     # aspp_4 is the spatial mean of an instance-normalised tensor: ~0 on both sides
     a4 = eng.get(P, "aspp_4").float().abs().max().item()
     assert a4 < (1e-5 if dtype == "f32" else 2e-3) and float(L["aspp_4"].abs().max()) < 1e-9
@@ -197,7 +202,7 @@ def test_shapes_other_than_64(oracle_run):
 
 # ------------------------------------------------------------------------------ CUTIE2 (configs 4 / 5): forward
 @pytest.mark.parametrize("variant,B,H,W,Hi", [("aspp", 2, 32, 48, 40), ("dilate", 1, 48, 32, 56)])
-@pytest.mark.parametrize("dtype", ["f32", "bf16", "f16"])
+@pytest.mark.parametrize("dtype", ["f32", "f16", "bf16"])
 def test_cutie2_forward_parity(variant, B, H, W, Hi, dtype):
     """CUTIE2-ASPP / CUTIE2-dilate inference: image branch (3x3 convs, its own ASPP), positional
     sampling of the image feature map at the token pixels, 1x1 fuser, the CUTIE-ASPP trunk.
@@ -232,7 +237,7 @@ def test_cutie2_forward_parity(variant, B, H, W, Hi, dtype):
     print(variant, dtype, "rel-L2 per layer", {k: "%.1e" % v for k, v in report.items()})
     # bf16: the same ~5e-3 per layer as CUTIE-ASPP, compounded over 21 / 26 layers (see the module
     # docstring); the bound is the measured level with margin, not the 2e-2 target
-    tol = {"f32": 1e-4, "bf16": 1.5e-1, "f16": 2e-2}[dtype]
+    tol = {"f32": 1e-4, "f16": HEADLINE_TOL, "bf16": BF16_OPTION_TOL_DEEP}[dtype]
     for name, e in report.items():
         assert e < tol, (name, e)
     if dtype in ("f32", "f16"):

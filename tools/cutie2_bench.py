@@ -59,7 +59,7 @@ def run(variant, B, H, W, V, C, dtype, mode, steps, warmup):
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
-    ap.add_argument("--dtype", default="bf16")
+    ap.add_argument("--dtype", default="f16")
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=12)
     ap.add_argument("--only", default="", help="'aspp32': config 4 at B = 32 alone, 'dilate8': config 5 training at B = 8 alone (for a profiler)")

@@ -13,7 +13,7 @@ dev = "cuda:0"
 V, E, C, H, W, B = 20000, 128, 18, 64, 64, 32
 p = types.SimpleNamespace(embedding_size=E, weight_decay=5e-4, hard_negative_ratio=3, batch_size=B)
 net = CUTIERes(V, C, p); net.build_loss()
-eng = Engine(net, dev, dtype="bf16", seed=0)
+eng = Engine(net, dev, dtype="f16", seed=0)
 tr = Trainer(eng)
 tok = {k: torch.from_numpy(v).to(dev) for k, v in make_documents(B, C, seed=1234).items()}
 def step():

@@ -2,14 +2,18 @@
 python tools/make_pmc_profile.py gpurun_out/<dir> profiles/<tag>_pmc.json"""
 import glob
 import json
+import os
 import subprocess
 import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from bench import kernel_source_sha  # noqa: E402
 
 src, dst = sys.argv[1], sys.argv[2]
 csvs = sorted(glob.glob(src + "/*/*/*_counter_collection.csv"))
 d = json.loads(subprocess.check_output([sys.executable, __file__.replace("make_pmc_profile", "pmc_summary")] + csvs))
 out = {"source": "tools/gpu_pmc.sh: three rocprofv3 --pmc passes (FETCH_SIZE | WRITE_SIZE | SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES "
-                 "SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_WAVE_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE), each over `python3 "
+                 "SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_WAVE_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE), each over `python3 "
                  "bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timing --no-f16` (23 steps), summarised by "
                  "tools/pmc_summary.py; per-launch averages",
        "correction": "hbm_bytes_per_launch = (2*FETCH_SIZE + WRITE_SIZE) * 1024: FETCH_SIZE and WRITE_SIZE are in KiB and gfx950 tallies a "
@@ -17,7 +21,7 @@ out = {"source": "tools/gpu_pmc.sh: three rocprofv3 --pmc passes (FETCH_SIZE | W
                      "that read 16 B per lane (convs, wgrad, norm passes); for 4-byte-per-lane readers (pack_batched, adam, l2, sumsq) "
                      "read hbm_bytes_raw = (FETCH_SIZE + WRITE_SIZE) * 1024 instead.",
        "mfma_util": "SQ_VALU_MFMA_BUSY_CYCLES / (4 * SQ_BUSY_CU_CYCLES)", "lds_conflict_share": "SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE",
-       "kernels": {}}
+       "source_sha": kernel_source_sha(), "kernels": {}}
 for k, v in d.items():
     if "FETCH_SIZE" not in v or "WRITE_SIZE" not in v:
         continue
@@ -26,7 +30,8 @@ for k, v in d.items():
          "hbm_bytes_per_launch": int((2 * f + w) * 1024), "hbm_bytes_raw": int((f + w) * 1024)}
     if "SQ_BUSY_CU_CYCLES" in v and v["SQ_BUSY_CU_CYCLES"]["avg"] > 0:
         e["mfma_util"] = round(v["SQ_VALU_MFMA_BUSY_CYCLES"]["avg"] / (4 * v["SQ_BUSY_CU_CYCLES"]["avg"]), 4)
-        e["mfma_gflop_issued_per_launch"] = round(v["SQ_INSTS_VALU_MFMA_MOPS_BF16"]["avg"] * 512 / 1e9, 2)
+        mops = v["SQ_INSTS_VALU_MFMA_MOPS_BF16"]["avg"] + v.get("SQ_INSTS_VALU_MFMA_MOPS_F16", {"avg": 0.0})["avg"]
+        e["mfma_gflop_issued_per_launch"] = round(mops * 512 / 1e9, 2)
         if v["SQ_LDS_IDX_ACTIVE"]["avg"] > 0:
             e["lds_conflict_share"] = round(v["SQ_LDS_BANK_CONFLICT"]["avg"] / v["SQ_LDS_IDX_ACTIVE"]["avg"], 4)
     if k.startswith("at::") or k.startswith("__amd"):

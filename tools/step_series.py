@@ -12,7 +12,7 @@ mode = sys.argv[1] if len(sys.argv) > 1 else "train"
 V, E, C, H, W, B = 20000, 128, 18, 64, 64, 32
 p = types.SimpleNamespace(embedding_size=E, weight_decay=5e-4, hard_negative_ratio=3, batch_size=B)
 net = CUTIERes(V, C, p); net.build_loss()
-eng = Engine(net, "cuda:0", dtype="bf16", seed=0)
+eng = Engine(net, "cuda:0", dtype="f16", seed=0)
 tr = Trainer(eng, learning_rate=1e-4 if mode == "train" else 0.0)
 packed = make_documents(B, C, seed=1234)
 tok = {k: torch.from_numpy(v).cuda() for k, v in packed.items()}
