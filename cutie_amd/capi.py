@@ -74,6 +74,7 @@ SIGNATURES = {
     "cutie_softmax_ce_fwd": (_i, [_vp, _i, _i, _vp, _i64, _i, _vp, _vp, _vp, _vp]),
     "cutie_hnm_workspace_bytes": (_sz, [_i64]),
     "cutie_hnm_weights": (_i, [_vp, _vp, _i64, _i, _vp, _vp, _vp, _sz, _vp]),
+    "cutie_hnm_weights_static": (_i, [_vp, _vp, _i64, _i, _vp, _vp, _vp]),
     "cutie_softmax_ce_bwd": (_i, [_vp, _vp, _vp, _i64, _i, _vp, _i, _i, _vp, _vp, _vp]),
     "cutie_ghm_state_bytes": (_sz, [_i]),
     "cutie_ghm_weights": (_i, [_vp, _i, _i, _vp, _i64, _i, _i, _f, _f, _vp, _sz, _vp, _vp, _vp]),

@@ -3,6 +3,8 @@
 // (/root/reference/model_cutie.py:107-130).  HBM-bound: (2C+2)*4 B per cell fwd+bwd.
 #include "common.h"
 
+#include <mutex>
+
 #include <math.h>
 
 namespace {
@@ -497,6 +499,22 @@ extern "C" size_t cutie_hnm_workspace_bytes(int64_t n_cells) {
     return (size_t)(HNM_INT_HEAD + 3 * hnm_chunks(n_cells)) * 4 + 64;
 }
 
+// the six launches of the select over a zero-filled work area `ws` (16-byte aligned, hnm_ws layout)
+static int hnm_launch(const float* ce, const int32_t* labels, int64_t n_cells, int ratio, float* weight, float* loss_out,
+                      void* ws, hipStream_t stream) {
+    const int chunks = (int)hnm_chunks(n_cells);
+    CUTIE_CHECK_HIP(hipMemsetAsync(ws, 0, (size_t)(HNM_INT_HEAD + 3 * chunks) * 4, stream));
+    const dim3 g(chunks), t(HNM_T);
+    hipLaunchKernelGGL(hnm_count_kernel, g, t, 0, stream, ce, labels, n_cells, chunks, ws);
+    hipLaunchKernelGGL(hnm_hist_kernel<1>, g, t, 0, stream, ce, labels, n_cells, chunks, ratio, ws);
+    hipLaunchKernelGGL(hnm_hist_kernel<2>, g, t, 0, stream, ce, labels, n_cells, chunks, ratio, ws);
+    hipLaunchKernelGGL(hnm_tie_kernel, g, t, 0, stream, ce, labels, n_cells, chunks, ratio, ws);
+    hipLaunchKernelGGL(hnm_weight_kernel, g, t, 0, stream, ce, labels, n_cells, chunks, ratio, ws, weight);
+    hipLaunchKernelGGL(hnm_final_kernel, dim3(1), dim3(64), 0, stream, chunks, ratio, ws, loss_out);
+    CUTIE_CHECK_LAUNCH();
+    return CUTIE_OK;
+}
+
 extern "C" int cutie_hnm_weights(const float* ce, const int32_t* labels, int64_t n_cells, int ratio, float* weight,
                                  float* loss_out, void* workspace, size_t workspace_bytes, cutie_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
@@ -509,17 +527,54 @@ extern "C" int cutie_hnm_weights(const float* ce, const int32_t* labels, int64_t
         return CUTIE_E_WORKSPACE;
     }
     void* ws = (void*)(((uintptr_t)workspace + 15) & ~(uintptr_t)15);
-    const int chunks = (int)hnm_chunks(n_cells);
-    CUTIE_CHECK_HIP(hipMemsetAsync(ws, 0, (size_t)(HNM_INT_HEAD + 3 * chunks) * 4, stream));
-    const dim3 g(chunks), t(HNM_T);
-    hipLaunchKernelGGL(hnm_count_kernel, g, t, 0, stream, ce, labels, n_cells, chunks, ws);
-    hipLaunchKernelGGL(hnm_hist_kernel<1>, g, t, 0, stream, ce, labels, n_cells, chunks, ratio, ws);
-    hipLaunchKernelGGL(hnm_hist_kernel<2>, g, t, 0, stream, ce, labels, n_cells, chunks, ratio, ws);
-    hipLaunchKernelGGL(hnm_tie_kernel, g, t, 0, stream, ce, labels, n_cells, chunks, ratio, ws);
-    hipLaunchKernelGGL(hnm_weight_kernel, g, t, 0, stream, ce, labels, n_cells, chunks, ratio, ws, weight);
-    hipLaunchKernelGGL(hnm_final_kernel, dim3(1), dim3(64), 0, stream, chunks, ratio, ws, loss_out);
-    CUTIE_CHECK_LAUNCH();
+    return hnm_launch(ce, labels, n_cells, ratio, weight, loss_out, ws, stream);
+}
+
+// ---------------------------------------------------------------------------------------------
+// cutie_hnm_weights for callers that cannot allocate (HIP graph capture, serving loops): the work area of the
+// select - three histograms, eight counters and three words per 1024-cell chunk - lives in a device array of the
+// code object instead of a caller workspace.  Each GPU the library runs on holds its own copy at its own address
+// until the process ends; the host only ever uses the address hipGetSymbolAddress returned for the CURRENT device
+// (the array's name is a host-side stand-in, never a device pointer).
+constexpr int64_t HNM_STATIC_MAX_CELLS = (int64_t)CUTIE_HNM_STATIC_MAX_CELLS;
+constexpr size_t HNM_STATIC_BYTES = (size_t)(HNM_INT_HEAD + 3 * (HNM_STATIC_MAX_CELLS / HNM_CHUNK)) * 4;
+static __device__ __align__(256) unsigned char g_hnm_scratch[HNM_STATIC_BYTES];
+
+namespace {
+constexpr int HNM_MAX_DEVICES = 64;
+std::mutex g_hnm_scratch_mu;
+void* g_hnm_scratch_ptr[HNM_MAX_DEVICES];      // per device, resolved on the entry point's first call there
+
+int hnm_scratch_for_current_device(void** out) {
+    int dev = -1;
+    CUTIE_CHECK_HIP(hipGetDevice(&dev));
+    CUTIE_CHECK_ARG(dev >= 0 && dev < HNM_MAX_DEVICES, "hnm_weights_static: device ordinal %d (max %d)", dev, HNM_MAX_DEVICES - 1);
+    std::lock_guard<std::mutex> lock(g_hnm_scratch_mu);
+    if (!g_hnm_scratch_ptr[dev]) {
+        void* p = nullptr;
+        CUTIE_CHECK_HIP(hipGetSymbolAddress(&p, HIP_SYMBOL(g_hnm_scratch)));
+        CUTIE_CHECK_ARG(p && ((uintptr_t)p & 15) == 0, "hnm_weights_static: symbol address %p", p);
+        g_hnm_scratch_ptr[dev] = p;
+    }
+    *out = g_hnm_scratch_ptr[dev];
     return CUTIE_OK;
+}
+}  // namespace
+
+extern "C" int cutie_hnm_weights_static(const float* ce, const int32_t* labels, int64_t n_cells, int ratio,
+                                        float* weight, float* loss_out, cutie_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    CUTIE_CHECK_ARG(n_cells >= 0 && ratio >= 0, "hnm_weights_static: n=%lld ratio=%d", (long long)n_cells, ratio);
+    CUTIE_CHECK_ARG(ce && labels && weight && loss_out, "hnm_weights_static: null pointer");
+    if (n_cells > HNM_STATIC_MAX_CELLS) {
+        cutie::set_error("hnm_weights_static: %lld cells exceed the static work area's %lld (use cutie_hnm_weights with a "
+                         "caller workspace)", (long long)n_cells, (long long)HNM_STATIC_MAX_CELLS);
+        return CUTIE_E_ARG;
+    }
+    void* ws = nullptr;
+    if (int e = hnm_scratch_for_current_device(&ws)) return e;
+    // the array keeps the last call's histograms: hnm_launch clears what this call's size uses before anything reads it
+    return hnm_launch(ce, labels, n_cells, ratio, weight, loss_out, ws, stream);
 }
 
 extern "C" int cutie_softmax_ce_bwd(const float* probs, const int32_t* labels, const float* weight, int64_t n_cells,

@@ -254,6 +254,17 @@ size_t cutie_hnm_workspace_bytes(int64_t n_cells);
 int cutie_hnm_weights(const float* ce, const int32_t* labels, int64_t n_cells, int ratio,
                       float* weight, float* loss_out, void* workspace, size_t workspace_bytes,
                       cutie_stream_t stream);
+/* cutie_hnm_weights without a workspace argument and without any allocation.  No counterpart in the
+ * reference: it is for callers that cannot allocate device memory - code under HIP graph capture, tight
+ * serving loops, harnesses that forbid hipMalloc.  Same kernels, same results bit for bit; the select's work
+ * area (histograms, counters, per-chunk words: 69 KB) is a device array of the library's code object, one copy
+ * per GPU for the life of the process.  n_cells <= CUTIE_HNM_STATIC_MAX_CELLS, else CUTIE_E_ARG.  The current
+ * device must be the one the pointers and the stream belong to.  Every call on a GPU shares that GPU's array
+ * (each call clears what it uses first): calls that overlap on one GPU - two streams, two threads - race.
+ * The first call on a device resolves the array's address (hipGetSymbolAddress): make it outside graph capture. */
+#define CUTIE_HNM_STATIC_MAX_CELLS (4 * 1024 * 1024)
+int cutie_hnm_weights_static(const float* ce, const int32_t* labels, int64_t n_cells, int ratio,
+                             float* weight, float* loss_out, cutie_stream_t stream);
 int cutie_softmax_ce_bwd(const float* probs, const int32_t* labels, const float* weight,
                          int64_t n_cells, int C, void* dlogits, int ld, int dtype,
                          const float* loss_scale /* nullable, see K12 */,
