@@ -40,6 +40,18 @@ struct ConvParams {
     float bw_eps;
     float* bw_red;           // [B][bw_red_tiles][n_out][2]
     int bw_red_tiles;
+    // Rendezvous of a sample's tiles inside such a data-gradient launch (conv_wide only, with bw_*; nullable): after
+    // publishing its slot of bw_red every tile waits until the sample's other tiles have published theirs, folds all
+    // slots and stores dz = act'(a) * inv * (dy - mean(dy) - xhat * mean(dy * xhat)) - what cutie_in_bwd_apply computes -
+    // instead of dy, plus its share of the bias gradient.  `out` is not written then.
+    unsigned* rv_cnt;        // [B][n_tiles_n] arrival counters, only ever incremented (zeroed once by the caller)
+    char* rv_dz;
+    int rv_ld_dz;
+    float* rv_dbias;         // [B][rv_dbias_tiles][n_out], tile t of a sample stores row t
+    int rv_dbias_tiles;
+    int rv_relu;             // 0 none, 1 ReLU mask a > 0
+    int rv_plain_order;      // 1: block ids in launch order (a sample's tiles spread over the XCDs)
+    int* rv_err;             // [1]: tiles whose bounded wait ran out (the step's results are then invalid)
     // conv_wide: order in which an XCD takes the pixel tiles of its samples - heaviest (most live taps)
     // first, so that the light corner tiles of a dilated layer fill the end of the launch.  0 = row-major.
     int perm_n;
@@ -119,5 +131,6 @@ __device__ __forceinline__ void glds16(u32x4s_t rsrc, unsigned lds_dst, unsigned
 // segment cin a multiple of 64
 int launch_conv_wide(const convk::ConvParams& p, int dtype, int bn, hipStream_t stream);
 int conv_wide_tile(const convk::ConvParams& p);
+bool conv_wide_rendezvous_ok(const convk::ConvParams& p, int bn, int* plain_order);
 
 }  // namespace cutie

@@ -765,6 +765,12 @@ struct NormBwd {      // the reduction of cutie_in_bwd_stats, asked of a data-gr
     float eps;
     float* red;
     int red_tiles;
+    // cutie_conv_dgrad_in_bwd: the second half of the norm's gradient as well (dz, bias-gradient partials)
+    void* dz;
+    int ld_dz, relu;
+    float* dbias;
+    int dbias_tiles;
+    unsigned* sync;      // word 0: tiles whose wait ran out; then [B][n tiles] arrival counters
 };
 }  // namespace
 
@@ -787,6 +793,7 @@ static int conv_fwd_impl(const cutie_conv_seg* segs, int n_segs, int B, int H, i
     ConvParams p;
     p.nseg = n_segs;
     p.bw_a = nullptr; p.bw_ld_a = 0; p.bw_stats = nullptr; p.bw_stats_tiles = 0; p.bw_eps = 0.f; p.bw_red = nullptr; p.bw_red_tiles = 0; p.perm_n = 0;
+    p.rv_cnt = nullptr; p.rv_dz = nullptr; p.rv_ld_dz = 0; p.rv_dbias = nullptr; p.rv_dbias_tiles = 0; p.rv_relu = 0; p.rv_plain_order = 0; p.rv_err = nullptr;
     int twb, th_g;
     generic_tiling(W, th_g, twb);
     p.TWB = twb;
@@ -845,12 +852,25 @@ static int conv_fwd_impl(const cutie_conv_seg* segs, int n_segs, int B, int H, i
             const bool fuse_on = cutie::config().fuse_norm_bwd;
             const bool fuse = nb && fuse_on && nb->a_dtype == dtype && (nb->ld_a * 2) % 16 == 0 && cutie::aligned16(nb->a) &&
                               q.tiles_h * q.tiles_w <= nb->red_tiles;
+            bool meet = false;
             if (fuse) {
                 q.bw_a = (const char*)nb->a; q.bw_ld_a = nb->ld_a; q.bw_stats = nb->stats; q.bw_stats_tiles = nb->stats_tiles;
                 q.bw_eps = nb->eps; q.bw_red = nb->red; q.bw_red_tiles = nb->red_tiles;
+                // the whole norm gradient inside this launch: a sample's tiles meet after publishing their sums
+                int plain = 0;
+                meet = nb->dz && nb->sync && cutie::config().rendezvous && nb->relu != 2 && (nb->ld_dz * 2) % 16 == 0 &&
+                       cutie::aligned16(nb->dz) && (!nb->dbias || q.tiles_h * q.tiles_w <= nb->dbias_tiles) &&
+                       cutie::conv_wide_rendezvous_ok(q, bn, &plain);
+                if (meet) {
+                    q.rv_err = reinterpret_cast<int*>(nb->sync); q.rv_cnt = nb->sync + 1;      // word 0: timeouts
+                    q.rv_dz = (char*)nb->dz; q.rv_ld_dz = nb->ld_dz; q.rv_dbias = nb->dbias; q.rv_dbias_tiles = nb->dbias_tiles;
+                    q.rv_relu = nb->relu; q.rv_plain_order = plain;
+                }
             }
             const int rc = cutie::launch_conv_wide(q, dtype, bn, stream);
-            if (rc != CUTIE_OK || fuse || !nb) return rc;
+            if (rc != CUTIE_OK) return rc;
+            if (meet) return 1;      // positive: dz and dbias are in place (callers inside this file only)
+            if (fuse || !nb) return rc;
             return cutie_in_bwd_stats(out, ld_out, out_dtype, nb->a, nb->ld_a, nb->a_dtype, nb->stats, nb->stats_tiles, nb->eps,
                                       nb->red, nb->red_tiles, B, H * W, n_out, stream_);
         }
@@ -892,8 +912,41 @@ extern "C" int cutie_conv_dgrad_in_stats(const cutie_conv_seg* segs, int n_segs,
                     red_tiles, H, W, cutie_conv_stats_tiles(H, W));
     CUTIE_CHECK_ARG((reinterpret_cast<uintptr_t>(stats) & 7) == 0 && (reinterpret_cast<uintptr_t>(red) & 7) == 0,
                     "conv_dgrad_in_stats: stats and red must be 8-byte aligned");
-    const NormBwd nb = {a, ld_a, a_dtype, stats, stats_tiles, eps, red, red_tiles};
+    const NormBwd nb = {a, ld_a, a_dtype, stats, stats_tiles, eps, red, red_tiles, nullptr, 0, 0, nullptr, 0, nullptr};
     return conv_fwd_impl(segs, n_segs, B, H, W, n_out, out, ld_out, out_dtype, nullptr, 0, nullptr, 0, dtype, &nb, stream_);
+}
+
+extern "C" size_t cutie_conv_sync_bytes(int B, int n_out) {
+    if (B < 0 || n_out < 1) return 0;
+    return ((size_t)B * (size_t)cutie::cdiv(n_out, 64) + 1) * sizeof(unsigned);
+}
+
+extern "C" int cutie_conv_dgrad_in_bwd(const cutie_conv_seg* segs, int n_segs, int B, int H, int W, int n_out, void* dy,
+                                       int ld_dy, const void* a, int ld_a, const float* stats, int stats_tiles, float eps,
+                                       float* red, int red_tiles, int relu, void* dz, int ld_dz, float* dbias_part,
+                                       int dbias_tiles, void* sync, size_t sync_bytes, int dtype, cutie_stream_t stream_) {
+    CUTIE_CHECK_ARG(B >= 0 && H >= 1 && W >= 1 && n_out >= 1, "conv_dgrad_in_bwd: bad sizes");
+    if (B == 0) return CUTIE_OK;
+    CUTIE_CHECK_ARG(dy && a && stats && red && dz && ld_dy >= n_out && ld_a >= n_out && ld_dz >= n_out,
+                    "conv_dgrad_in_bwd: null pointer or leading dimension < n_out");
+    CUTIE_CHECK_ARG(relu >= 0 && relu <= 2, "conv_dgrad_in_bwd: activation code %d", relu);
+    CUTIE_CHECK_ARG(stats_tiles >= 1 && red_tiles >= cutie_conv_stats_tiles(H, W) && red_tiles <= 65535,
+                    "conv_dgrad_in_bwd: stats_tiles=%d, red_tiles=%d (>= cutie_conv_stats_tiles(%d, %d) = %d)", stats_tiles,
+                    red_tiles, H, W, cutie_conv_stats_tiles(H, W));
+    CUTIE_CHECK_ARG(!dbias_part || (dbias_tiles >= 1 && dbias_tiles <= 65535), "conv_dgrad_in_bwd: dbias_tiles=%d", dbias_tiles);
+    CUTIE_CHECK_ARG((reinterpret_cast<uintptr_t>(stats) & 7) == 0 && (reinterpret_cast<uintptr_t>(red) & 7) == 0,
+                    "conv_dgrad_in_bwd: stats and red must be 8-byte aligned");
+    if (sync && (sync_bytes < cutie_conv_sync_bytes(B, n_out) || (reinterpret_cast<uintptr_t>(sync) & 3))) {
+        cutie::set_error("conv_dgrad_in_bwd: sync area %zu < %zu bytes", sync_bytes, cutie_conv_sync_bytes(B, n_out));
+        return CUTIE_E_WORKSPACE;
+    }
+    const NormBwd nb = {a, ld_a, dtype, stats, stats_tiles, eps, red, red_tiles, dz, ld_dz, relu, dbias_part, dbias_tiles,
+                        (unsigned*)sync};
+    const int rc = conv_fwd_impl(segs, n_segs, B, H, W, n_out, dy, ld_dy, dtype, nullptr, 0, nullptr, 0, dtype, &nb, stream_);
+    if (rc == 1) return CUTIE_OK;      // one launch did all of it
+    if (rc != CUTIE_OK) return rc;
+    return cutie_in_bwd_apply(dy, ld_dy, dtype, a, ld_a, dtype, stats, stats_tiles, eps, red, red_tiles, relu, dz, ld_dz,
+                              dtype, dbias_part, dbias_tiles, B, H * W, n_out, stream_);
 }
 
 extern "C" size_t cutie_conv_wgrad_workspace_bytes(int B, int H, int W, int cin, int cout, int kh, int kw) {

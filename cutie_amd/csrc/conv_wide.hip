@@ -21,6 +21,7 @@
 //     data gradient into an instance-normalised layer - that layer's backward sums (sum dy, sum dy * xhat)
 //     taken in the same store pass (ConvParams::bw_*), so no separate reduction pass reads dy and a again.
 #include "conv_common.h"
+#include <type_traits>
 
 namespace cutie {
 namespace {
@@ -73,6 +74,7 @@ __device__ __forceinline__ void conv_wide_epilogue(const ConvParams& p, float4_t
     constexpr int IT = 256 / RG;         // store iterations per lane: 16 / 8 / 4
     const int pc = tid % PPR, rg = tid / PPR;
     const bool bw = p.bw_a != nullptr;
+    const bool rv = bw && p.rv_cnt != nullptr;
 
     // the forward activation pieces and the forward moments are requested first: their latency passes
     // under the staging of the accumulators
@@ -161,6 +163,7 @@ __device__ __forceinline__ void conv_wide_epilogue(const ConvParams& p, float4_t
             g2[e] = 0.f;
         }
     }
+    uint4 gvk[IT];                       // rendezvous: the tile's rounded dy stays in registers for the second pass
 #pragma unroll
     for (int k = 0; k < IT; ++k) {
         const int ml = rg + k * RG;
@@ -168,8 +171,12 @@ __device__ __forceinline__ void conv_wide_epilogue(const ConvParams& p, float4_t
         const int h = h0 + mb / TCB, w = w0 + (mb % TCB) * 16 + (ml & 15);
         if (h < H && w < W && col < n_out) {
             const uint4 gv = *reinterpret_cast<const uint4*>(Cs + ml * BN + pc * 8);
-            TO* dst = reinterpret_cast<TO*>(p.out) + ((long long)(b * H + h) * W + w) * p.ld_out + col;
-            *reinterpret_cast<uint4*>(dst) = gv;
+            if (rv) {
+                gvk[k] = gv;
+            } else {
+                TO* dst = reinterpret_cast<TO*>(p.out) + ((long long)(b * H + h) * W + w) * p.ld_out + col;
+                *reinterpret_cast<uint4*>(dst) = gv;
+            }
             if (bw) {
                 float g[8], x[8];
                 unpack8<DT>(gv, g);
@@ -196,11 +203,102 @@ __device__ __forceinline__ void conv_wide_epilogue(const ConvParams& p, float4_t
             s1 += v.x;
             s2 += v.y;
         }
-        *reinterpret_cast<float2*>(p.bw_red + (((long long)b * p.bw_red_tiles + tile) * n_out + n0 + tid) * 2) = make_float2(s1, s2);
+        float* slot = p.bw_red + (((long long)b * p.bw_red_tiles + tile) * n_out + n0 + tid) * 2;
+        if (rv) {
+            // other workgroups read this slot inside this launch: write-through 8-byte store (global_store_dwordx2 sc1;
+            // a wave's 64 lanes cover whole 128-byte lines), MI355X_MICROARCH.md "Valid forms", third row of the table
+            const unsigned long long bits = ((unsigned long long)__float_as_uint(s2) << 32) | __float_as_uint(s1);
+            __hip_atomic_store(reinterpret_cast<unsigned long long*>(slot), bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            *reinterpret_cast<float2*>(slot) = make_float2(s1, s2);
+        }
+    }
+    if (!rv) return;
+
+    // ---- rendezvous: every storing wave drains its stores, the workgroup meets, ONE lane announces the tile and
+    // polls the sample's counter (bounded), the workgroup meets again, then everybody reads the sample's slots by
+    // sc1 loads.  The counter only grows: a launch adds exactly T to it per sample, so the target is the next
+    // multiple of T above the value the add returned.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    const int T = p.tiles_h * p.tiles_w;
+    if (tid == 0) {
+        unsigned* cnt = p.rv_cnt + (long long)b * p.n_tiles_n + (n0 / BN);
+        const unsigned old = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned target = old - old % (unsigned)T + (unsigned)T;
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();      // 100 MHz
+        bool ok = true;
+        while ((int)(__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {
+            __builtin_amdgcn_s_sleep(8);
+            if (__builtin_amdgcn_s_memrealtime() - t0 > 20000000ull) {      // 0.2 s: the other tiles never came
+                ok = false;
+                break;
+            }
+        }
+        if (!ok) atomicAdd(p.rv_err, 1);
+    }
+    __syncthreads();
+    float* tab2 = reinterpret_cast<float*>(smem + S::WSUM);      // [2][BN]: mean(dy), mean(dy * xhat)
+    if (tid < BN && n0 + tid < n_out) {
+        float r1 = 0.f, r2 = 0.f;
+        const float inv_n = 1.f / (float)(H * W);
+#pragma unroll 4
+        for (int t = 0; t < p.bw_red_tiles; ++t) {      // slot order, as norm.hip's fold
+            const unsigned* q = reinterpret_cast<const unsigned*>(p.bw_red + (((long long)b * p.bw_red_tiles + t) * n_out + n0 + tid) * 2);
+            r1 += __uint_as_float(__hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            r2 += __uint_as_float(__hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        }
+        tab2[tid] = r1 * inv_n;
+        tab2[BN + tid] = r2 * inv_n;
+    }
+    __syncthreads();
+    float sb[8];
+    {
+        float m1[8], m2[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            m1[e] = tab2[pc * 8 + e];
+            m2[e] = tab2[BN + pc * 8 + e];
+            sb[e] = 0.f;
+        }
+#pragma unroll
+        for (int k = 0; k < IT; ++k) {
+            const int ml = rg + k * RG;
+            const int mb = ml >> 4;
+            const int h = h0 + mb / TCB, w = w0 + (mb % TCB) * 16 + (ml & 15);
+            if (h < H && w < W && col < n_out) {
+                float g[8], x[8];
+                unpack8<DT>(gvk[k], g);
+                unpack8<DT>(av[k], x);
+                TO o[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {     // the arithmetic of in_bwd_apply_kernel, operation for operation
+                    const float xh = (x[e] - mean8[e]) * inv8[e];
+                    float d = inv8[e] * (g[e] - m1[e] - xh * m2[e]);
+                    if (p.rv_relu == 1 && !(x[e] > 0.f)) d = 0.f;
+                    sb[e] += d;
+                    store_from_f32(&o[e], d);
+                }
+                TO* dst = reinterpret_cast<TO*>(p.rv_dz) + ((long long)(b * H + h) * W + w) * p.rv_ld_dz + col;
+                *reinterpret_cast<uint4*>(dst) = *reinterpret_cast<const uint4*>(o);
+            }
+        }
+    }
+    if (!p.rv_dbias) return;
+    __syncthreads();
+    float* rbf = reinterpret_cast<float*>(smem);        // [RG][BN]
+#pragma unroll
+    for (int e = 0; e < 8; ++e) rbf[rg * BN + pc * 8 + e] = sb[e];
+    __syncthreads();
+    if (tid < BN && n0 + tid < n_out) {
+        float s = 0.f;
+#pragma unroll 4
+        for (int r = 0; r < RG; ++r) s += rbf[r * BN + tid];
+        p.rv_dbias[((long long)b * p.rv_dbias_tiles + tile) * n_out + n0 + tid] = s;
     }
 }
 
-template <int DT, int BN>
+template <int DT, int BN, bool STG>
 __global__ __launch_bounds__(CW_NT) void conv_wide_kernel(ConvParams p) {
     typedef Shape<BN> S;
     constexpr int MB = S::MB, NB = S::NB, NP = S::NP;
@@ -230,7 +328,7 @@ __global__ __launch_bounds__(CW_NT) void conv_wide_kernel(ConvParams p) {
         th = tile / p.tiles_w;
         tw = tile - th * p.tiles_w;
     } else {
-        if ((nwg & 7) == 0) bid = (bid & 7) * (nwg >> 3) + (bid >> 3);
+        if ((nwg & 7) == 0 && !p.rv_plain_order) bid = (bid & 7) * (nwg >> 3) + (bid >> 3);
         nt = bid % p.n_tiles_n; bid /= p.n_tiles_n;
         tw = bid % p.tiles_w; bid /= p.tiles_w;
         th = bid % p.tiles_h;
@@ -270,6 +368,11 @@ __global__ __launch_bounds__(CW_NT) void conv_wide_kernel(ConvParams p) {
         b_rd[kk] = (wn * 64 + li) * 128 + c16;
     }
     int buf = 0;
+    uint4 bf0[4], af0[MB], bf1[4], af1[MB];      // K-half 0 / 1 fragments; a staggered wave keeps half 1 across the barrier
+    // the two orders are two separate instances of the whole K loop (one branch per kernel, none per step)
+    auto run = [&](auto stag_tag) {
+    constexpr bool stag = decltype(stag_tag)::value;
+    bool pend = false;                           // a staggered wave owes the second K half of its last step
 
     for (int s = 0; s < p.nseg; ++s) {
         const Seg g = p.seg[s];
@@ -321,17 +424,23 @@ __global__ __launch_bounds__(CW_NT) void conv_wide_kernel(ConvParams p) {
                 glds16(rsrc_w, lds0 + CW_B0 + bsel * S::BBUF + wave * (NB * 1024) + k * 1024, b_base[k] + db);
             }
         };
-        auto compute = [&](int bsel, auto prefetch) {
+        // first-half fragments; a staggered wave takes the upper half of its A fragments later (first_half, m == 0),
+        // so that they are not live beside the previous step's second-half fragments (register budget)
+        auto load_f0 = [&](int bsel, int m_end) {
             const char* At = smem + CW_A0 + bsel * CW_ABUF;
             const char* Bt = smem + CW_B0 + bsel * S::BBUF;
-            uint4 bf0[4], af0[MB], bf1[4], af1[MB];
 #pragma unroll
             for (int n = 0; n < 4; ++n) bf0[n] = *reinterpret_cast<const uint4*>(Bt + b_rd[0] + n * 2048);
 #pragma unroll
-            for (int m = 0; m < MB; ++m) af0[m] = *reinterpret_cast<const uint4*>(At + a_rd[0] + m * 2048);
-            // first K half: between the groups of 4 MFMAs the pieces of the next step's tiles are
-            // sent on their way and the second half's fragments are fetched; the scheduling
-            // barriers keep hipcc from gathering the loads into one burst
+            for (int m = 0; m < MB; ++m)
+                if (m < m_end) af0[m] = *reinterpret_cast<const uint4*>(At + a_rd[0] + m * 2048);
+        };
+        // first K half: between the groups of 4 MFMAs the pieces of the next step's tiles are
+        // sent on their way and the second half's fragments are fetched; the scheduling
+        // barriers keep hipcc from gathering the loads into one burst
+        auto first_half = [&](int bsel, auto prefetch) {
+            const char* At = smem + CW_A0 + bsel * CW_ABUF;
+            const char* Bt = smem + CW_B0 + bsel * S::BBUF;
 #pragma unroll
             for (int m = 0; m < MB; ++m) {
 #ifndef CW_ISSUE_MODE
@@ -342,6 +451,10 @@ __global__ __launch_bounds__(CW_NT) void conv_wide_kernel(ConvParams p) {
                     if (CW_ISSUE_MODE == 0 && (q * MB) / NP == m) prefetch(q);            // spread over the first K half
                     if (CW_ISSUE_MODE == 1 && (q * MB) / (2 * NP) == m) prefetch(q);      // first quarter, two per group
                     if (CW_ISSUE_MODE == 2 && m == 0) prefetch(q);                        // burst before the first MFMA
+                }
+                if (stag && m == 0 && MB > 1) {
+#pragma unroll
+                    for (int k = (MB + 1) / 2; k < MB; ++k) af0[k] = *reinterpret_cast<const uint4*>(At + a_rd[0] + k * 2048);
                 }
                 if (m == MB / 2 - 1) {
 #pragma unroll
@@ -356,10 +469,38 @@ __global__ __launch_bounds__(CW_NT) void conv_wide_kernel(ConvParams p) {
                 for (int n = 0; n < 4; ++n) mma_frag<DT>(af0[m], bf0[n], acc[m][n]);
                 __builtin_amdgcn_sched_barrier(0);
             }
+        };
+        // second K half, from registers; the staggered waves issue the next step's pieces between its groups
+        auto second_half = [&](auto prefetch) {
 #pragma unroll
-            for (int m = 0; m < MB; ++m)
+            for (int m = 0; m < MB; ++m) {
+#pragma unroll
+                for (int q = 0; q < NP; ++q)
+                    if ((q * MB) / (2 * NP) == m) prefetch(q);
 #pragma unroll
                 for (int n = 0; n < 4; ++n) mma_frag<DT>(af1[m], bf1[n], acc[m][n]);
+            }
+        };
+        auto compute = [&](int bsel, auto prefetch) {
+            load_f0(bsel, (stag && MB > 1) ? (MB + 1) / 2 : MB);
+            if constexpr (stag) {
+                if (pend) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    second_half(prefetch);
+                    __builtin_amdgcn_sched_barrier(0);
+                } else {
+#pragma unroll
+                    for (int q = 0; q < NP; ++q) prefetch(q);
+                }
+                first_half(bsel, [&](int) {});
+                pend = true;
+                // the reads of this step's second-half fragments must have left LDS before the barrier that lets
+                // the next pieces overwrite the buffer (the MFMAs that wait for them come after it)
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            } else {
+                first_half(bsel, prefetch);
+                second_half([&](int) {});
+            }
         };
 
         // ---- software pipeline over the live (tap, channel chunk) steps of this segment
@@ -400,6 +541,15 @@ __global__ __launch_bounds__(CW_NT) void conv_wide_kernel(ConvParams p) {
         compute(buf, [&](int) {});
         buf ^= 1;
     }
+    if (stag && pend) {
+#pragma unroll
+        for (int m = 0; m < MB; ++m)
+#pragma unroll
+            for (int n = 0; n < 4; ++n) mma_frag<DT>(af1[m], bf1[n], acc[m][n]);
+    }
+    };
+    if (STG && wave >= 4) run(std::true_type{});
+    else run(std::false_type{});
 
     conv_wide_epilogue<DT, BN>(p, acc, smem, b, th * p.tiles_w + tw, h0, w0, n0);
 }
@@ -425,23 +575,24 @@ int conv_wide_tile(const ConvParams& p) {
 template <int DT, int BN>
 static int launch_one(const ConvParams& p, hipStream_t stream) {
     const long long grid = (long long)p.B * p.tiles_h * p.tiles_w * p.n_tiles_n;
-    CUTIE_ENSURE_LDS((conv_wide_kernel<DT, BN>), Shape<BN>::LDS);
-    hipLaunchKernelGGL((conv_wide_kernel<DT, BN>), dim3((unsigned)grid), dim3(CW_NT), Shape<BN>::LDS, stream, p);
+    if (config().conv_stagger) {
+        CUTIE_ENSURE_LDS((conv_wide_kernel<DT, BN, true>), Shape<BN>::LDS);
+        hipLaunchKernelGGL((conv_wide_kernel<DT, BN, true>), dim3((unsigned)grid), dim3(CW_NT), Shape<BN>::LDS, stream, p);
+    } else {
+        CUTIE_ENSURE_LDS((conv_wide_kernel<DT, BN, false>), Shape<BN>::LDS);
+        hipLaunchKernelGGL((conv_wide_kernel<DT, BN, false>), dim3((unsigned)grid), dim3(CW_NT), Shape<BN>::LDS, stream, p);
+    }
     CUTIE_CHECK_LAUNCH();
     return CUTIE_OK;
 }
 
-// Heaviest-first tile order (ConvParams::perm): the K steps of a tile are its live taps x channel chunks, which on
-// a dilated layer differ up to 2x between the centre and the corners of the image.  Dispatch is in block order, so
-// putting the heavy tiles first lets the light ones even out the end of the launch.
-static void plan_tile_order(ConvParams& p) {
-    const bool on = config().conv_lpt;
-    p.perm_n = 0;
+// K steps of every pixel tile (live taps x channel chunks); returns false when there are more tiles than CONV_MAX_PERM
+static bool tile_weights(const ConvParams& p, int* weight, int& wmin, int& wmax) {
     const int nt = p.tiles_h * p.tiles_w;
-    if (!on || nt < 2 || nt > CONV_MAX_PERM || (p.B & 7) != 0) return;
+    if (nt > CONV_MAX_PERM) return false;
     const int TR = p.TH, TC = p.TWB * 16;
-    int weight[CONV_MAX_PERM];
-    int wmin = 1 << 30, wmax = 0;
+    wmin = 1 << 30;
+    wmax = 0;
     for (int t = 0; t < nt; ++t) {
         const int h0 = (t / p.tiles_w) * TR, w0 = (t % p.tiles_w) * TC;
         int w = 0;
@@ -463,6 +614,46 @@ static void plan_tile_order(ConvParams& p) {
         if (w < wmin) wmin = w;
         if (w > wmax) wmax = w;
     }
+    return true;
+}
+
+// A rendezvous of a sample's tiles is deadlock-free when all of a sample's workgroups can be resident together: one
+// 8-wave workgroup per CU, dispatched in block order, so at most 32 a sample where the block order keeps a sample on
+// one XCD and at most 128 where it spreads them (plain_order); a bounded wait in the kernel backs this up.  It pays
+// when what the tiles wait for each other (every round of workgroups lasts as long as its heaviest tile, and the
+// heaviest-first order is given up) costs less than the pass over dy, a and dz it replaces (6 bytes per element at
+// ~5 TB/s); a K step of the 256 tile takes ~1.4 us (conv_wide).
+bool conv_wide_rendezvous_ok(const ConvParams& p, int bn, int* plain_order) {
+    int weight[CONV_MAX_PERM];
+    int wmin, wmax;
+    if (!tile_weights(p, weight, wmin, wmax)) return false;
+    const int nt = p.tiles_h * p.tiles_w;
+    const int per_sample = nt * p.n_tiles_n;
+    if (per_sample > 128) return false;
+    double wavg = 0.0;
+    for (int t = 0; t < nt; ++t) wavg += weight[t];
+    wavg /= nt;
+    const double rounds = (double)((long long)p.B * per_sample + 255) / 256.0;
+    const double step_us = 1.4 * bn / 256.0;
+    const double cost_us = (rounds < 1.0 ? 1.0 : rounds) * (wmax - wavg) * step_us;
+    const double saved_us = 6.0 * p.B * p.H * p.W * p.n_out / 5e6;
+    if (cost_us > 0.6 * saved_us) return false;
+    *plain_order = per_sample > 32 ? 1 : 0;
+    return true;
+}
+
+// Heaviest-first tile order (ConvParams::perm): the K steps of a tile are its live taps x channel chunks, which on
+// a dilated layer differ up to 2x between the centre and the corners of the image.  Dispatch is in block order, so
+// putting the heavy tiles first lets the light ones even out the end of the launch.
+static void plan_tile_order(ConvParams& p) {
+    const bool on = config().conv_lpt;
+    p.perm_n = 0;
+    const int nt = p.tiles_h * p.tiles_w;
+    if (p.rv_cnt) return;      // a rendezvous wants a sample's tiles side by side in dispatch order
+    if (!on || nt < 2 || nt > CONV_MAX_PERM || (p.B & 7) != 0) return;
+    int weight[CONV_MAX_PERM];
+    int wmin, wmax;
+    tile_weights(p, weight, wmin, wmax);
     if (wmin == wmax) return;
     for (int t = 0; t < nt; ++t) p.perm[t] = (unsigned char)t;
     for (int i = 1; i < nt; ++i) {          // stable insertion sort, heaviest first

@@ -15,7 +15,7 @@ static bool env_on(const char* name) {
     const char* v = getenv(name);
     return !(v && atoi(v) == 0);
 }
-static const Config g_config = {env_on("CUTIE_CONV_WIDE"), env_on("CUTIE_FUSE_NORM_BWD"), env_on("CUTIE_CONV_LPT")};
+static const Config g_config = {env_on("CUTIE_CONV_WIDE"), env_on("CUTIE_FUSE_NORM_BWD"), env_on("CUTIE_CONV_LPT"), env_on("CUTIE_RENDEZVOUS"), env_on("CUTIE_CONV_STAGGER")};
 const Config& config() { return g_config; }
 
 // hipFuncAttributeMaxDynamicSharedMemorySize is a property of (kernel, device): set when a kernel first needs more

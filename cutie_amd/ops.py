@@ -11,6 +11,7 @@ from . import capi
 from .capi import BF16, F32, ConvSeg, call, dt_of, ld_of, ptr, stream
 
 IN_EPS = 1e-6  # tf.contrib.layers.instance_norm default epsilon (model_framework.py:423)
+ACTIVATION_CODE = {None: 0, False: 0, "none": 0, True: 1, "relu": 1, "sigmoid": 2}
 
 
 def _bke(dt):
@@ -130,7 +131,55 @@ def replay_sum_rows(batches, B, device, accumulate=False):
         call("cutie_sum_rows_batched", arr, len(arr), B, 1 if accumulate else 0, stream(device))
 
 
-ACTIVATION_CODE = {None: 0, False: 0, "none": 0, True: 1, "relu": 1, "sigmoid": 2}
+
+def _seg_array(segs, out, n_out, what):
+    B, H, W = out.shape[0], out.shape[1], out.shape[2]
+    arr = (ConvSeg * len(segs))()
+    dt = None
+    for i, s in enumerate(segs):
+        x, w = s["x"], s["w"]
+        sdt = dt_of(x)
+        if dt is None:
+            dt = sdt
+        if sdt != dt or dt_of(w) != dt:
+            raise capi.CutieError("%s: segment dtypes differ" % what)
+        if x.shape[0] != B or x.shape[1] != H or x.shape[2] != W:
+            raise capi.CutieError("%s: segment %d spatial shape %s != out %s" % (what, i, tuple(x.shape), tuple(out.shape)))
+        cin = s["cin"]
+        if w.shape[2] != cin or x.shape[3] < cin and ld_of(x) < cin:
+            raise capi.CutieError("%s: segment %d cin=%d, w %s, x %s" % (what, i, cin, tuple(w.shape), tuple(x.shape)))
+        n_off = s.get("n_off", 0)
+        if n_off + n_out > w.shape[1] or w.shape[0] != s["kh"] * s["kw"]:
+            raise capi.CutieError("%s: segment %d weight rows %d < %d+%d" % (what, i, w.shape[1], n_off, n_out))
+        arr[i].x = ptr(x)
+        arr[i].w = ptr(w) + n_off * cin * w.element_size()
+        arr[i].w_tap_stride = w.shape[1] * w.shape[2]
+        arr[i].ld_x = ld_of(x)
+        arr[i].cin = cin
+        arr[i].kh, arr[i].kw, arr[i].dil = s["kh"], s["kw"], s["dil"]
+        arr[i].flip = 1 if s.get("flip") else 0
+    return arr, dt
+
+
+def conv_sync_bytes(B, n_out):
+    return capi.lib().cutie_conv_sync_bytes(int(B), int(n_out))
+
+
+def conv_dgrad_in_bwd(segs, dy, n_out, a, stats, red, dz, dbias_part=None, relu=True, sync=None, eps=IN_EPS):
+    """Data gradient of an instance-normalised layer and the gradient of its norm + activation in one call
+    (cutie_conv_dgrad_in_bwd): segs as conv_fwd (flip=True), dy = scratch view [B,H,W,>=n_out], a / stats = the layer's
+    forward activation and moments, red = f32 [B,T,n_out,2] zeroed once, dz = output view, dbias_part f32 [B*T', n_out],
+    sync = int32 tensor of conv_sync_bytes(B, n_out) bytes zeroed once and dedicated to this layer and shape
+    (None: two-call form).  sync[0] counts tiles whose bounded wait ran out."""
+    B = dy.shape[0]
+    arr, dt = _seg_array(segs, dy, n_out, "conv_dgrad_in_bwd")
+    if dt_of(dy) != dt or dt_of(a) != dt or dt_of(dz) != dt:
+        raise capi.CutieError("conv_dgrad_in_bwd: dy, a and dz must have the segments' dtype")
+    call("cutie_conv_dgrad_in_bwd", arr, len(segs), B, dy.shape[1], dy.shape[2], n_out, ptr(dy), ld_of(dy), ptr(a), ld_of(a),
+         ptr(stats), _tiles(stats, B, n_out, True), eps, ptr(red), _tiles(red, B, n_out, True), ACTIVATION_CODE[relu],
+         ptr(dz), ld_of(dz), ptr(dbias_part), _tiles(dbias_part, B, n_out, False), ptr(sync),
+         sync.numel() * sync.element_size() if sync is not None else 0, dt, stream())
+    return dz
 
 
 def conv_fwd(segs, out, n_out, bias=None, relu=False, stats=None, norm_bwd=None):

@@ -196,7 +196,7 @@ class Engine(object):
         tiles = {n.name: ops.conv_stats_tiles(*spatial(n)) for n in convs}
         n_stats = sum(B * tiles[n.name] * n.channels * 2 for n in convs)
         P.stats_all = torch.zeros(n_stats, dtype=torch.float32, device=dev)
-        P.a, P.stats, P.red, P.dz, P.dy, P.dbpart = {}, {}, {}, {}, {}, {}
+        P.a, P.stats, P.red, P.dz, P.dy, P.dbpart, P.sync = {}, {}, {}, {}, {}, {}, {}
         so = 0
         for n in convs:
             hs, ws = spatial(n)
@@ -233,9 +233,13 @@ class Engine(object):
             t = ops.in_tiles(B, hs * ws, n.channels)       # H*W slices per sample of the two backward reductions
             # (sum dy, sum dy*xhat) slots: filled by the data gradient's own epilogue (one slot per conv tile;
             # the rest stay zero) or by in_bwd_stats (all of them)
-            P.red[n.name] = torch.zeros((B, ops.conv_stats_tiles(hs, ws), n.channels, 2), dtype=torch.float32,
-                                        device=dev)
-            P.dbpart[n.name] = torch.zeros((B * t, n.channels), dtype=torch.float32, device=dev)
+            ct = ops.conv_stats_tiles(hs, ws)
+            P.red[n.name] = torch.zeros((B, ct, n.channels, 2), dtype=torch.float32, device=dev)
+            # the one-launch data gradient (conv_dgrad_in_bwd) leaves one bias-gradient row per conv tile
+            fusable = n.name != net.loss_logits_name and self.dt != F32
+            P.dbpart[n.name] = torch.zeros((B * (max(ct, t) if fusable else t), n.channels), dtype=torch.float32, device=dev)
+            # arrival counters of that launch's tile rendezvous (word 0: timeouts); zeroed once, then the library's
+            P.sync[n.name] = torch.zeros(ops.conv_sync_bytes(B, n.channels) // 4, dtype=torch.int32, device=dev)
         # gradient buffers for every tensor that a conv, the embedding or the sampler produces
         P.ps_acc = {}
         for n in net.nodes:
@@ -293,8 +297,9 @@ class Engine(object):
         return [c for c in P.consumers.get(name, []) if c.op == "positional_sampling" and c.inputs[0].name == name]
 
     def _backprop_into(self, P, n):
-        """dy of node n's output from everything that consumes it.  Returns True when the launch also
-        left the instance-norm backward sums of n in P.red[n.name] (conv nodes: in_bwd_stats is then done)."""
+        """dy of node n's output from everything that consumes it.  For a conv node fed by convs the call goes all
+        the way to dz (data gradient + the gradient of the node's instance norm and activation, one launch where
+        the tiles can meet): returns True then, and loss_backward skips in_bwd_stats / in_bwd_apply."""
         segs = self._grad_segments(P, n.name)
         samplers = self._sampler_consumers(P, n.name)
         if samplers:
@@ -310,8 +315,10 @@ class Engine(object):
             ops.convert(acc.view(P.B, P.Hi, P.W, C), P.dy[n.name][..., :C])
         elif segs:
             if n.op == "conv":
-                ops.conv_fwd(segs, P.dy[n.name], n.channels,
-                             norm_bwd=(P.a[n.name][..., :n.channels], P.stats[n.name], P.red[n.name]))
+                ops.conv_dgrad_in_bwd(segs, P.dy[n.name][..., :n.channels], n.channels, P.a[n.name][..., :n.channels],
+                                      P.stats[n.name], P.red[n.name], P.dz[n.name][..., :n.channels],
+                                      dbias_part=P.dbpart[n.name], relu=n.attrs.get("activation", "relu"),
+                                      sync=P.sync[n.name])
                 return True
             ops.conv_fwd(segs, P.dy[n.name], n.channels)
         return False
@@ -388,6 +395,11 @@ class Engine(object):
     def check_inputs(self, P):
         """Host-side validation of the counters the kernels keep (one sync)."""
         oob, bad = int(P.oob.item()), int(P.bad.item()) if P.has_labels else 0
+        late = sum(int(s[0].item()) for s in P.sync.values()) if P.bwd_ready else 0
+        if late:
+            raise CutieError("%d conv tiles gave up waiting for their sample's other tiles (the GPU could not hold a "
+                             "sample's workgroups at once): the gradients since the last check are invalid; set "
+                             "CUTIE_RENDEZVOUS=0 before loading the library" % late)
         if oob:
             raise CutieError("%d grid cells hold a vocabulary id outside [0, %d) (SURVEY.md 0.7)" % (oob, self.net.num_vocabs))
         if bad:
@@ -442,13 +454,13 @@ class Engine(object):
         for n in reversed(net.nodes):
             if n.op == "conv":
                 a = n.attrs
-                have_red = self._backprop_into(P, n) if n.name != lname else False
-                dy = P.dy[n.name][..., :n.channels]
-                av = P.a[n.name][..., :n.channels]
-                if not have_red:
+                have_dz = self._backprop_into(P, n) if n.name != lname else False
+                if not have_dz:
+                    dy = P.dy[n.name][..., :n.channels]
+                    av = P.a[n.name][..., :n.channels]
                     ops.in_bwd_stats(dy, av, P.stats[n.name], P.red[n.name])
-                ops.in_bwd_apply(dy, av, P.stats[n.name], P.red[n.name], P.dz[n.name][..., :n.channels],
-                                 dbias_part=P.dbpart[n.name], relu=a.get("activation", "relu"))
+                    ops.in_bwd_apply(dy, av, P.stats[n.name], P.red[n.name], P.dz[n.name][..., :n.channels],
+                                     dbias_part=P.dbpart[n.name], relu=a.get("activation", "relu"))
                 src = n.inputs[0]
                 if side is not None:
                     # dz of this layer is final: its weight gradient (and, data-parallel, the L2 term and the

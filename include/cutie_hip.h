@@ -152,6 +152,31 @@ int cutie_conv_dgrad_in_stats(const cutie_conv_seg* segs /* host */, int n_segs,
                               float* red, int red_tiles,
                               int dtype, cutie_stream_t stream);
 
+/* The data gradient of such a layer AND the whole gradient of its instance norm and activation, i.e.
+ * cutie_conv_dgrad_in_stats followed by cutie_in_bwd_apply (K6 below), asked for as one call:
+ *   dz = act'(a) * inv * (dy - mean(dy) - xhat * mean(dy * xhat)),  dbias_part[b*dbias_tiles + t][c] = partial sums of dz.
+ * Where the wide MFMA kernel applies, the tiles of a sample take about equally long and at most 128 workgroups
+ * make up a sample, ONE launch does it: every tile publishes its slot of `red`, the sample's tiles meet on a
+ * counter in `sync` (a bounded wait), fold the slots and store dz straight from the tile - dy is never written and
+ * the pass over dy, a and dz does not run (the same bits as the two-call form: same operands, same order).
+ * Otherwise the call runs the two-call form through `dy`.  Either way `dy` must be a valid [B,H,W,>=n_out] scratch.
+ *   sync: cutie_conv_sync_bytes(B, n_out) bytes, 4-byte aligned, zeroed ONCE by the caller and then left to the
+ *         library, one area per (layer, shape): its counters only grow, by the tile count per launch.  Word 0 counts
+ *         tiles whose wait ran out (0.2 s: a sample's workgroups were not resident together) - the results of such a
+ *         launch are invalid; read it at a synchronisation point.  NULL selects the two-call form.
+ *   dbias_part (nullable): dbias_tiles >= cutie_conv_stats_tiles(H, W); tile t of a sample STORES row t, rows the
+ *         launch does not own are left alone (zero the array once when it is allocated), as for `red`.
+ * CUTIE_RENDEZVOUS=0 in the environment when the library is loaded selects the two-call form everywhere. */
+size_t cutie_conv_sync_bytes(int B, int n_out);
+int cutie_conv_dgrad_in_bwd(const cutie_conv_seg* segs /* host */, int n_segs,
+                            int B, int H, int W, int n_out,
+                            void* dy, int ld_dy,
+                            const void* a, int ld_a, const float* stats, int stats_tiles, float eps,
+                            float* red, int red_tiles, int relu,
+                            void* dz, int ld_dz, float* dbias_part, int dbias_tiles,
+                            void* sync, size_t sync_bytes,
+                            int dtype, cutie_stream_t stream);
+
 /* weight gradient: dw[(i*kw+j)][c][n] (= HWIO, model_framework.py:416) =
  *   sum over b,h,w of x[b, h+(i-kh/2)*dil, w+(j-kw/2)*dil, c] * dz[b,h,w,n].
  * Deterministic: K is split over `splits` row groups into f32 slabs in the workspace, then

@@ -131,7 +131,7 @@ def init_params(graph, num_vocabs, embedding_size, num_classes, seed=0, dtype=to
     return params
 
 
-def forward(graph, params, grid, image, ps_1d_indices, activation="relu", masks=None):
+def forward(graph, params, grid, image, ps_1d_indices, activation="relu", masks=None, pre=None):
     """grid int [B,H,W]; image [B,Hi,W,3]; ps_1d_indices int [B,H*W] -> dict of every named layer.
     masks: optional layer name -> 0/1 ReLU pattern (see cutie_oracle.cbrn)."""
     if grid.dim() == 4:
@@ -143,7 +143,7 @@ def forward(graph, params, grid, image, ps_1d_indices, activation="relu", masks=
         elif op == "conv":
             act = activation if name == "cls_logits" else "relu"
             L[name] = cbrn(L[inputs[0]], params[name + "/weights"], params[name + "/biases"], args[3], activation=act,
-                           mask=masks.get(name) if masks else None)
+                           mask=masks.get(name) if masks else None, pre=pre, name=name)
         elif op == "concat":
             L[name] = torch.cat([L[i] for i in inputs], dim=3)
         elif op == "global_pool":
@@ -160,7 +160,8 @@ def loss_and_grads(graph, params, grid, image, ps_1d_indices, labels, hard_negat
     """model_cutie2.py:114-147 (the same loss as model_cutie.py:107-140) + tf.gradients of total_loss
     w.r.t. every variable, by autograd over the restated graph."""
     ps = OrderedDict((k, v.detach().clone().requires_grad_(True)) for k, v in params.items())
-    layers = forward(graph, ps, grid, image, ps_1d_indices, masks=masks)
+    pre = OrderedDict()
+    layers = forward(graph, ps, grid, image, ps_1d_indices, masks=masks, pre=pre)
     for t in layers.values():
         if torch.is_tensor(t) and t.requires_grad:
             t.retain_grad()
@@ -168,4 +169,5 @@ def loss_and_grads(graph, params, grid, image, ps_1d_indices, labels, hard_negat
     total.backward()
     return {"model_loss": model_loss.detach(), "reg_loss": reg.detach(), "total_loss": total.detach(), "layers": layers,
             "grads": OrderedDict((k, v.grad) for k, v in ps.items()),
-            "dlayers": OrderedDict((k, t.grad) for k, t in layers.items() if torch.is_tensor(t) and t.grad is not None)}
+            "dlayers": OrderedDict((k, t.grad) for k, t in layers.items() if torch.is_tensor(t) and t.grad is not None),
+            "dpre": OrderedDict((k, t.grad) for k, t in pre.items() if t.grad is not None)}

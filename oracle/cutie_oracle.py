@@ -47,12 +47,16 @@ def conv_raw(x, w_hwio, rate=1):
     return y.permute(0, 2, 3, 1)
 
 
-def cbrn(x, w_hwio, bias, rate=1, activation="relu", mask=None):
+def cbrn(x, w_hwio, bias, rate=1, activation="relu", mask=None, pre=None, name=None):
     """mask (optional, relu only): a 0/1 tensor that replaces the ReLU's own activation pattern
     (a = z * mask).  Tests pass the DEVICE's pattern so that gradients are compared on the same
     side of every ReLU kink; a pre-activation within rounding of 0 otherwise flips the whole
     local gradient and says nothing about the backward kernels."""
     z = conv_raw(x, w_hwio, rate) + bias
+    if pre is not None:             # the pre-activation conv + b: its gradient is what the device calls dz
+        if z.requires_grad:
+            z.retain_grad()
+        pre[name] = z
     if mask is not None and activation == "relu":
         a = z * mask
     else:
@@ -112,7 +116,7 @@ def init_params(num_vocabs, embedding_size, num_classes, seed=0, dtype=torch.flo
     return params
 
 
-def aspp_forward(params, grid, activation="relu", masks=None):
+def aspp_forward(params, grid, activation="relu", masks=None, pre=None):
     """grid int [B,H,W] or [B,H,W,1] -> dict of every named layer (model_cutie_aspp.py:35-74)."""
     if grid.dim() == 4:
         grid = grid[..., 0]
@@ -122,19 +126,21 @@ def aspp_forward(params, grid, activation="relu", masks=None):
     x = L["embedding"]
     for name in ("encoder1_1", "encoder1_2", "encoder1_3", "encoder1_4", "encoder1_5", "encoder1_6",
                  "encoder1_7", "encoder1_8"):
-        x = cbrn(x, params[name + "/weights"], params[name + "/biases"], ASPP_LAYERS[name][3], mask=m(name))
+        x = cbrn(x, params[name + "/weights"], params[name + "/biases"], ASPP_LAYERS[name][3], mask=m(name), pre=pre, name=name)
         L[name] = x
     e8 = L["encoder1_8"]
     for name in ("aspp_1", "aspp_2", "aspp_3"):
-        L[name] = cbrn(e8, params[name + "/weights"], params[name + "/biases"], ASPP_LAYERS[name][3], mask=m(name))
+        L[name] = cbrn(e8, params[name + "/weights"], params[name + "/biases"], ASPP_LAYERS[name][3], mask=m(name),
+                       pre=pre, name=name)
     L["aspp_4"] = global_pool(e8)
     L["aspp_concat"] = torch.cat([L["aspp_1"], L["aspp_2"], L["aspp_3"], L["aspp_4"]], dim=3)
-    L["aspp_1x1"] = cbrn(L["aspp_concat"], params["aspp_1x1/weights"], params["aspp_1x1/biases"], mask=m("aspp_1x1"))
+    L["aspp_1x1"] = cbrn(L["aspp_concat"], params["aspp_1x1/weights"], params["aspp_1x1/biases"], mask=m("aspp_1x1"),
+                           pre=pre, name="aspp_1x1")
     L["concat1"] = torch.cat([L["encoder1_1"], L["aspp_1x1"]], dim=3)
     L["decoder1_1"] = cbrn(L["concat1"], params["decoder1_1/weights"], params["decoder1_1/biases"],
-                           mask=m("decoder1_1"))
+                           mask=m("decoder1_1"), pre=pre, name="decoder1_1")
     L["cls_logits"] = cbrn(L["decoder1_1"], params["cls_logits/weights"], params["cls_logits/biases"],
-                           activation=activation, mask=m("cls_logits"))
+                           activation=activation, mask=m("cls_logits"), pre=pre, name="cls_logits")
     L["softmax"] = torch.softmax(L["cls_logits"], dim=-1)
     return L
 
@@ -221,7 +227,8 @@ def loss_and_grads(params, grid, labels, hard_negative_ratio=3, weight_decay=5e-
                    activation="relu", ghm_weights=None):
     """activation='sigmoid' + ghm_weights: the use_ghm = 1 graph (model_cutie_aspp.py:17,73; model_cutie.py:110)"""
     ps = OrderedDict((k, v.detach().clone().requires_grad_(True)) for k, v in params.items())
-    layers = aspp_forward(ps, grid, activation=activation, masks=masks)
+    pre = OrderedDict()
+    layers = aspp_forward(ps, grid, activation=activation, masks=masks, pre=pre)
     for t in layers.values():
         if t.requires_grad:
             t.retain_grad()
@@ -231,7 +238,8 @@ def loss_and_grads(params, grid, labels, hard_negative_ratio=3, weight_decay=5e-
     grads = OrderedDict((k, v.grad) for k, v in ps.items())
     return {"model_loss": model_loss.detach(), "reg_loss": reg.detach(), "total_loss": total.detach(),
             "layers": layers, "grads": grads, "d_embedding_out": layers["embedding"].grad,
-            "dlayers": OrderedDict((k, t.grad) for k, t in layers.items() if t.grad is not None)}
+            "dlayers": OrderedDict((k, t.grad) for k, t in layers.items() if t.grad is not None),
+            "dpre": OrderedDict((k, t.grad) for k, t in pre.items() if t.grad is not None)}
 
 
 def global_norm_tf(grads, d_embedding_out):

@@ -409,6 +409,82 @@ def test_conv_dgrad_in_stats(ops, dt, case):
     assert torch.equal(dy, dy2) and torch.equal(red, red2)
 
 
+DGRAD_BWD_CASES = [
+    # B, H, W, channels of the consuming conv's output, channels of dy, dil, activation
+    (32, 64, 64, 64, 256, 1, "relu"),    # the bench shape: 16 tiles a sample, a sample's tiles on one XCD, two rounds of workgroups
+    (5, 64, 64, 64, 256, 2, "relu"),     # grid not a multiple of 8: a sample's tiles spread over the XCDs
+    (3, 42, 63, 64, 256, 1, "relu"),     # ragged tiles
+    (8, 32, 64, 64, 128, 4, "none"),     # channel tile 128; no activation
+    (4, 40, 64, 128, 64, 1, "relu"),     # channel tile 64
+    (2, 7, 80, 64, 512, 2, "relu"),      # two channel tiles of 256: two counters per sample
+    (8, 64, 64, 64, 256, 16, "relu"),    # unbalanced tiles (dilation 16) with a short K loop: either form
+    (32, 64, 64, 256, 256, 16, "relu"),  # the same with the model's K loop: the entry point takes the two-call form itself
+    (2, 12, 64, 64, 36, 1, "relu"),      # not a wide-kernel shape: two-call form
+    (1, 160, 128, 64, 128, 1, "relu"),   # 80 tiles x 1 channel tile a sample: plain block order
+]
+
+
+@pytest.mark.parametrize("dt", ["bf16", "f16", "f32"])
+@pytest.mark.parametrize("case", DGRAD_BWD_CASES)
+def test_conv_dgrad_in_bwd_matches_the_two_call_form(ops, dt, case):
+    """cutie_conv_dgrad_in_bwd with a sync area (one launch, the sample's tiles meet inside it) against the same entry
+    point without one (data gradient, then cutie_in_bwd_apply): dz bit for bit - same operands, same order - and the
+    bias-gradient partials up to the order of the f32 additions.  Five launches in a row on fresh data each: a slot or
+    a counter read stale from a cache would show as a mismatch; the counters must have advanced by the tile count."""
+    B, H, W, cz, C, dil, act = case
+    g = torch.Generator().manual_seed(hash(case[:6]) % 1000 + 5)
+    tdt = TDT[dt]
+    w = (torch.randn((3, 5, C, cz), generator=g) * 0.05).to(tdt).float()
+    _, wd = ops.pack_weights(w.to(DEV), CDT[dt], want_fwd=False)
+    if wd.shape[2] != cz:
+        pytest.skip("padded cin")
+    ld = (C + 15) // 8 * 8
+    T = ops.conv_stats_tiles(H, W)
+    sync = torch.zeros(ops.conv_sync_bytes(B, C) // 4, dtype=torch.int32, device=DEV)
+    red = torch.zeros((B, T, C, 2), dtype=torch.float32, device=DEV)
+    dbp = torch.zeros((B * T, C), dtype=torch.float32, device=DEV)
+    stats = torch.zeros((B, 3, C, 2), dtype=torch.float32, device=DEV)
+    for it in range(5):
+        dzin = _rand_act(g, (B, H, W, cz), tdt).to(DEV)
+        a = torch.relu(torch.randn((B, H, W, C), generator=g) + 0.2 * it).to(tdt)
+        ad = torch.zeros((B, H, W, ld), dtype=tdt, device=DEV)
+        ad[..., :C] = a.to(DEV)
+        ops.in_stats(ad[..., :C], stats)
+        seg = [dict(x=dzin, w=wd, cin=wd.shape[2], kh=3, kw=5, dil=dil, flip=True)]
+        dy_ref = torch.zeros((B, H, W, ld), dtype=tdt, device=DEV)
+        dz_ref = torch.full((B, H, W, ld), 3.0, dtype=tdt, device=DEV)
+        red_ref = torch.zeros((B, T, C, 2), dtype=torch.float32, device=DEV)
+        dbp_ref = torch.zeros((B * T, C), dtype=torch.float32, device=DEV)
+        ops.conv_dgrad_in_bwd(seg, dy_ref[..., :C], C, ad[..., :C], stats, red_ref, dz_ref[..., :C], dbias_part=dbp_ref,
+                              relu=act, sync=None)
+        dy = torch.zeros((B, H, W, ld), dtype=tdt, device=DEV)
+        dz = torch.full((B, H, W, ld), 3.0, dtype=tdt, device=DEV)
+        ops.conv_dgrad_in_bwd(seg, dy[..., :C], C, ad[..., :C], stats, red, dz[..., :C], dbias_part=dbp, relu=act, sync=sync)
+        torch.cuda.synchronize()
+        assert int(sync[0]) == 0, "a tile's wait ran out"
+        assert torch.equal(dz.view(torch.int16) if dt != "f32" else dz, dz_ref.view(torch.int16) if dt != "f32" else dz_ref), it
+        db, db_ref = dbp.view(B, T, C).sum(dim=1), dbp_ref.view(B, T, C).sum(dim=1)
+        scale = dz_ref[..., :C].float().abs().sum(dim=(1, 2))
+        assert float(((db - db_ref).abs() / (scale + 1e-20)).max()) < 1e-5, it
+    met = sync[1:].cpu()
+    if int(met.abs().sum()) > 0:                       # the one-launch form ran: every counter advanced by 5 x tiles
+        per = int(met[met != 0][0])
+        assert per % 5 == 0 and bool(((met == per) | (met == 0)).all())
+        assert dt != "f32" and float(dy.float().abs().max()) == 0.0      # and dy was never written
+    else:
+        assert dt == "f32" or case[5] == 16 or case[4] == 36      # only those may take the two-call form
+    # against float64 of the same rounded operands (last iteration)
+    a64, d64 = ad[..., :C].double().cpu(), dy_ref[..., :C].double().cpu()
+    mean = a64.mean(dim=(1, 2), keepdim=True)
+    var = ((a64 - mean) ** 2).mean(dim=(1, 2), keepdim=True)
+    inv = 1.0 / torch.sqrt(var + 1e-6)
+    xh = (a64 - mean) * inv
+    ref = inv * (d64 - d64.mean(dim=(1, 2), keepdim=True) - xh * (d64 * xh).mean(dim=(1, 2), keepdim=True))
+    if act == "relu":
+        ref = ref * (a64 > 0)
+    assert relerr(dz[..., :C], ref) < {"f32": 1e-4, "f16": 2e-3, "bf16": 1.2e-2}[dt]
+
+
 @pytest.mark.parametrize("dt", ["f32", "bf16", "f16"])
 def test_conv_dgrad_multi_segment(ops, dt):
     """d(loss)/dx of a tensor consumed by two convs (3x5 dil 2 with 128 outputs, and channels

@@ -134,7 +134,10 @@ def test_cutie_aspp_forward_backward_parity(oracle_run, dtype):
                                  r["labels"], 3)
     sel_diff = int(((P.weight.cpu() != 0) != (w_ref != 0)).sum())
     print(dtype, "hard-negative selection: cells that differ from the oracle's:", sel_diff)
-    derr = {k: rel(P.dy[k][..., :g.shape[-1]].double() / S, g) for k, g in o["dlayers"].items() if k in P.dy and k != "encoder1_8"}
+    # gradient of every conv's pre-activation (the device's dz; the one-launch data gradient writes no dy) and of
+    # the embedding output
+    derr = {k: rel(P.dz[k][..., :g.shape[-1]].double() / S, g) for k, g in o["dpre"].items()}
+    derr["embedding"] = rel(P.dy["embedding"][..., :E].double() / S, o["dlayers"]["embedding"])
     print(dtype, "d(layer) errors", {k: "%.2e" % v for k, v in derr.items()})
     gerr = {k: rel(eng.grads[k], g) for k, g in o["grads"].items()}
     gerr["aspp_1x1/weights"] = rel(eng.grads["aspp_1x1/weights"][:, :, :768], o["grads"]["aspp_1x1/weights"][:, :, :768])
@@ -306,7 +309,9 @@ def test_cutie2_backward_parity(variant, B, H, W, Hi, dtype):
     assert abs(rg - float(o["reg_loss"])) < 1e-4 * abs(float(o["reg_loss"]))
     sampled = "image_featuremap" if variant == "aspp" else "image_encoder1_8"
     dl = {k: rel2(P.dy[k][..., :o["dlayers"][k].shape[-1]].double() / S, o["dlayers"][k])[0]
-          for k in ("positional_sampling", sampled, "image_encoder1_1", "feature_fuser", "embedding")}
+          for k in ("positional_sampling", sampled, "embedding")}
+    dl.update({"dz " + k: rel2(P.dz[k][..., :o["dpre"][k].shape[-1]].double() / S, o["dpre"][k])[0]
+               for k in (sampled, "image_encoder1_1", "feature_fuser", "encoder1_4")})
     print(variant, dtype, "d(layer) rel-L2", {k: "%.1e" % v for k, v in dl.items()})
     gerr = {k: rel2(eng.grads[k], gr)[0] for k, gr in o["grads"].items()}
     print(variant, dtype, "grad rel-L2", {k: "%.1e" % v for k, v in gerr.items()})
