@@ -51,6 +51,7 @@ struct ConvParams {
     int rv_dbias_tiles;
     int rv_relu;             // 0 none, 1 ReLU mask a > 0
     int rv_plain_order;      // 1: block ids in launch order (a sample's tiles spread over the XCDs)
+    int rv_nowait;           // diagnostic (CUTIE_RV_NOWAIT=1): do not wait - WRONG results, prices the protocol without the waiting
     int* rv_err;             // [1]: tiles whose bounded wait ran out (the step's results are then invalid)
     // conv_wide: order in which an XCD takes the pixel tiles of its samples - heaviest (most live taps)
     // first, so that the light corner tiles of a dilated layer fill the end of the launch.  0 = row-major.

@@ -793,7 +793,7 @@ static int conv_fwd_impl(const cutie_conv_seg* segs, int n_segs, int B, int H, i
     ConvParams p;
     p.nseg = n_segs;
     p.bw_a = nullptr; p.bw_ld_a = 0; p.bw_stats = nullptr; p.bw_stats_tiles = 0; p.bw_eps = 0.f; p.bw_red = nullptr; p.bw_red_tiles = 0; p.perm_n = 0;
-    p.rv_cnt = nullptr; p.rv_dz = nullptr; p.rv_ld_dz = 0; p.rv_dbias = nullptr; p.rv_dbias_tiles = 0; p.rv_relu = 0; p.rv_plain_order = 0; p.rv_err = nullptr;
+    p.rv_cnt = nullptr; p.rv_dz = nullptr; p.rv_ld_dz = 0; p.rv_dbias = nullptr; p.rv_dbias_tiles = 0; p.rv_relu = 0; p.rv_plain_order = 0; p.rv_err = nullptr; p.rv_nowait = 0;
     int twb, th_g;
     generic_tiling(W, th_g, twb);
     p.TWB = twb;
@@ -864,7 +864,7 @@ static int conv_fwd_impl(const cutie_conv_seg* segs, int n_segs, int B, int H, i
                 if (meet) {
                     q.rv_err = reinterpret_cast<int*>(nb->sync); q.rv_cnt = nb->sync + 1;      // word 0: timeouts
                     q.rv_dz = (char*)nb->dz; q.rv_ld_dz = nb->ld_dz; q.rv_dbias = nb->dbias; q.rv_dbias_tiles = nb->dbias_tiles;
-                    q.rv_relu = nb->relu; q.rv_plain_order = plain;
+                    q.rv_relu = nb->relu; q.rv_plain_order = plain; q.rv_nowait = cutie::config().rv_nowait ? 1 : 0;
                 }
             }
             const int rc = cutie::launch_conv_wide(q, dtype, bn, stream);

@@ -228,7 +228,7 @@ __device__ __forceinline__ void conv_wide_epilogue(const ConvParams& p, float4_t
         const unsigned target = old - old % (unsigned)T + (unsigned)T;
         const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();      // 100 MHz
         bool ok = true;
-        while ((int)(__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {
+        while (!p.rv_nowait && (int)(__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {
             __builtin_amdgcn_s_sleep(8);
             if (__builtin_amdgcn_s_memrealtime() - t0 > 20000000ull) {      // 0.2 s: the other tiles never came
                 ok = false;
@@ -242,11 +242,23 @@ __device__ __forceinline__ void conv_wide_epilogue(const ConvParams& p, float4_t
     if (tid < BN && n0 + tid < n_out) {
         float r1 = 0.f, r2 = 0.f;
         const float inv_n = 1.f / (float)(H * W);
-#pragma unroll 4
-        for (int t = 0; t < p.bw_red_tiles; ++t) {      // slot order, as norm.hip's fold
-            const unsigned* q = reinterpret_cast<const unsigned*>(p.bw_red + (((long long)b * p.bw_red_tiles + t) * n_out + n0 + tid) * 2);
-            r1 += __uint_as_float(__hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-            r2 += __uint_as_float(__hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        // slot order, as norm.hip's fold; sixteen slots' loads are in flight together (one memory round trip, not four)
+        for (int t0 = 0; t0 < p.bw_red_tiles; t0 += 16) {
+            unsigned v1[16], v2[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const int t = t0 + u < p.bw_red_tiles ? t0 + u : p.bw_red_tiles - 1;
+                const unsigned* q = reinterpret_cast<const unsigned*>(p.bw_red + (((long long)b * p.bw_red_tiles + t) * n_out + n0 + tid) * 2);
+                v1[u] = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                v2[u] = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                if (t0 + u < p.bw_red_tiles) {
+                    r1 += __uint_as_float(v1[u]);
+                    r2 += __uint_as_float(v2[u]);
+                }
+            }
         }
         tab2[tid] = r1 * inv_n;
         tab2[BN + tid] = r2 * inv_n;
@@ -622,7 +634,7 @@ static bool tile_weights(const ConvParams& p, int* weight, int& wmin, int& wmax)
 // one XCD and at most 128 where it spreads them (plain_order); a bounded wait in the kernel backs this up.  It pays
 // when what the tiles wait for each other (every round of workgroups lasts as long as its heaviest tile, and the
 // heaviest-first order is given up) costs less than the pass over dy, a and dz it replaces (6 bytes per element at
-// ~5 TB/s); a K step of the 256 tile takes ~1.4 us (conv_wide).
+// ~5 TB/s); a K step of the 256 tile takes ~1.9 us of a tile's wall time (tools/dgrad_bench.py: 230 us for two rounds of 60 steps).
 bool conv_wide_rendezvous_ok(const ConvParams& p, int bn, int* plain_order) {
     int weight[CONV_MAX_PERM];
     int wmin, wmax;
@@ -634,10 +646,10 @@ bool conv_wide_rendezvous_ok(const ConvParams& p, int bn, int* plain_order) {
     for (int t = 0; t < nt; ++t) wavg += weight[t];
     wavg /= nt;
     const double rounds = (double)((long long)p.B * per_sample + 255) / 256.0;
-    const double step_us = 1.4 * bn / 256.0;
+    const double step_us = 1.9 * bn / 256.0;
     const double cost_us = (rounds < 1.0 ? 1.0 : rounds) * (wmax - wavg) * step_us;
     const double saved_us = 6.0 * p.B * p.H * p.W * p.n_out / 5e6;
-    if (cost_us > 0.6 * saved_us) return false;
+    if (cost_us > 0.5 * saved_us) return false;      // the launch's own protocol takes the other half (tools/dgrad_bench.py)
     *plain_order = per_sample > 32 ? 1 : 0;
     return true;
 }

@@ -11,11 +11,11 @@ namespace cutie {
 static thread_local std::string g_last_error;
 
 // A/B switches of the measurement scripts, read ONCE when the library is loaded (never per call)
-static bool env_on(const char* name) {
+static bool env_on(const char* name, bool dflt = true) {
     const char* v = getenv(name);
-    return !(v && atoi(v) == 0);
+    return v ? atoi(v) != 0 : dflt;
 }
-static const Config g_config = {env_on("CUTIE_CONV_WIDE"), env_on("CUTIE_FUSE_NORM_BWD"), env_on("CUTIE_CONV_LPT"), env_on("CUTIE_RENDEZVOUS"), env_on("CUTIE_CONV_STAGGER")};
+static const Config g_config = {env_on("CUTIE_CONV_WIDE"), env_on("CUTIE_FUSE_NORM_BWD"), env_on("CUTIE_CONV_LPT"), env_on("CUTIE_RENDEZVOUS"), env_on("CUTIE_RV_NOWAIT", false), env_on("CUTIE_CONV_STAGGER", false)};
 const Config& config() { return g_config; }
 
 // hipFuncAttributeMaxDynamicSharedMemorySize is a property of (kernel, device): set when a kernel first needs more
