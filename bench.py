@@ -46,12 +46,27 @@ def conv_launch_flops(segs, B, H, W, n_out):
 
 
 class ConvTimer(object):
-    """Wraps ops.conv_fwd: brackets every launch with HIP events on the launch stream."""
+    """Wraps ops.conv_fwd and ops.conv_dgrad_in_bwd: brackets every forward / data-gradient conv launch with HIP
+    events on the launch stream.  A data gradient that also carries the instance-norm gradient (the one-launch form)
+    is timed as a whole and credited with the conv's FLOPs only; the two layers per step whose call falls back to the
+    two-call form (dilation 16) have the norm pass inside their bracket - the fraction reads low, never high."""
 
     def __init__(self, ops):
-        self.ops, self.orig = ops, ops.conv_fwd
+        self.ops, self.orig, self.orig_bwd = ops, ops.conv_fwd, ops.conv_dgrad_in_bwd
         self.events, self.flops, self.enabled = [], [], False
         ops.conv_fwd = self
+        ops.conv_dgrad_in_bwd = self.dgrad_in_bwd
+
+    def dgrad_in_bwd(self, segs, dy, n_out, *a, **kw):
+        if not self.enabled:
+            return self.orig_bwd(segs, dy, n_out, *a, **kw)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        r = self.orig_bwd(segs, dy, n_out, *a, **kw)
+        e1.record()
+        self.events.append((e0, e1))
+        self.flops.append(conv_launch_flops(segs, dy.shape[0], dy.shape[1], dy.shape[2], n_out))
+        return r
 
     # Timing events serialise the queue (each one is a barrier packet): bracketing all 28 conv
     # launches of every step costs ~6 % of the step.  So only every EVERY-th timed step is

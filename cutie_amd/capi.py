@@ -85,8 +85,8 @@ SIGNATURES = {
     "cutie_sumsq": (_i, [_vp, _i64, _i, _vp, _vp, _vp, _vp]),
     "cutie_loss_scale_init": (_i, [_vp, _f, _vp]),
     "cutie_loss_scale_update": (_i, [_vp, _vp, _f, _f, _i, _f, _f, _vp]),
-    "cutie_adam_step": (_i, [_vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _vp, _f, _f, _vp]),
-    "cutie_batch_gather": (_i, [_vp, _i, _i, _vp, _i, _i, _i, _vp, _i, _i, _vp]),
+    "cutie_adam_step": (_i, [_vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _vp, _f, _f, _i, _vp, _vp]),
+    "cutie_batch_gather": (_i, [_vp, _i, _i, _vp, _i, _i, _i, _vp, _i, _i, _vp, _vp]),
     "cutie_batch_scatter_add": (_i, [_vp, _i, _i, _vp, _i, _i, _i, _i, _vp, _vp]),
     "cutie_convert": (_i, [_vp, _i, _i, _vp, _i, _i, _i64, _i, _vp]),
 }

@@ -155,7 +155,8 @@ template <int DT>
 __global__ __launch_bounds__(256) void batch_gather_kernel(const typename elem<DT>::type* __restrict__ feat,
                                                            int ld_feat, int n_src, const int32_t* __restrict__ idx,
                                                            int n_cells, int B, int C4,
-                                                           typename elem<DT>::type* __restrict__ out, int ld_out) {
+                                                           typename elem<DT>::type* __restrict__ out, int ld_out,
+                                                           int32_t* __restrict__ oob) {
     const int64_t total = (int64_t)B * n_cells * C4;
     for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total;
          t += (int64_t)gridDim.x * blockDim.x) {
@@ -163,6 +164,7 @@ __global__ __launch_bounds__(256) void batch_gather_kernel(const typename elem<D
         const int q = (int)(t - cell * C4);
         const int b = (int)(cell / n_cells);
         int s = idx[cell];
+        if (oob && q == 0 && (s < 0 || s >= n_src)) atomicAdd(oob, 1);      // tf.batch_gather raises; here it is counted
         s = s < 0 ? 0 : (s >= n_src ? n_src - 1 : s);
         const float4 v = load4(feat + ((int64_t)b * n_src + s) * ld_feat + q * 4);
         store4(out + cell * ld_out + q * 4, v);
@@ -311,7 +313,8 @@ extern "C" int cutie_embed_bwd(const int32_t* ids, int64_t n_cells, const void* 
 }
 
 extern "C" int cutie_batch_gather(const void* feat, int ld_feat, int n_src, const int32_t* idx, int n_cells,
-                                  int B, int C, void* out, int ld_out, int dtype, cutie_stream_t stream_) {
+                                  int B, int C, void* out, int ld_out, int dtype, int32_t* oob_count,
+                                  cutie_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     CUTIE_CHECK_ARG(B >= 0 && n_cells >= 0 && n_src >= 1 && C >= 4 && (C % 4) == 0, "batch_gather: bad sizes");
     CUTIE_CHECK_ARG((ld_feat % 4) == 0 && (ld_out % 4) == 0 && ld_feat >= C && ld_out >= C, "batch_gather: bad ld");
@@ -321,7 +324,7 @@ extern "C" int cutie_batch_gather(const void* feat, int ld_feat, int n_src, cons
     CUTIE_DISPATCH_DTYPE(dtype, DT,
         hipLaunchKernelGGL(batch_gather_kernel<DT>, dim3(g), dim3(256), 0, stream,
                            (const typename elem<DT>::type*)feat, ld_feat, n_src, idx, n_cells, B, C / 4,
-                           (typename elem<DT>::type*)out, ld_out));
+                           (typename elem<DT>::type*)out, ld_out, oob_count));
     CUTIE_CHECK_LAUNCH();
     return CUTIE_OK;
 }

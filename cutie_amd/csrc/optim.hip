@@ -86,8 +86,17 @@ __global__ void loss_scale_update_kernel(float* __restrict__ state, const float*
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                    float* __restrict__ m, float* __restrict__ v, int64_t n, float lr_t,
                                                    float b1, float b2, float eps, const float* __restrict__ gnorm_sq,
-                                                   float clip, float grad_scale) {
+                                                   float clip, float grad_scale, int t,
+                                                   const float* __restrict__ loss_scale) {
     float scale = grad_scale;
+    if (loss_scale && t > 0) {
+        // steps the device skipped (f16 overflow) never reached m and v: the bias correction belongs to the count of
+        // steps that did, t - skipped, not to the caller's t (lr_t = lr * c(t), c(t) = sqrt(1 - b2^t) / (1 - b1^t))
+        const double te = fmax((double)t - (double)loss_scale[3], 1.0);
+        const double c_t = sqrt(1.0 - pow((double)b2, (double)t)) / (1.0 - pow((double)b1, (double)t));
+        const double c_e = sqrt(1.0 - pow((double)b2, te)) / (1.0 - pow((double)b1, te));
+        lr_t = (float)((double)lr_t * (c_e / c_t));
+    }
     // an overflowed (f16, loss-scaled) backward shows as a non-finite norm: leave p, m, v untouched
     if (gnorm_sq && !(fabsf(*gnorm_sq) <= 3.0e38f)) return;
     if (gnorm_sq) {
@@ -187,7 +196,7 @@ extern "C" int cutie_loss_scale_update(float* state, const float* gnorm_sq, floa
 
 extern "C" int cutie_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr_t, float beta1,
                                float beta2, float eps, const float* gnorm_sq, float clip, float grad_scale,
-                               cutie_stream_t stream_) {
+                               int t, const float* loss_scale, cutie_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     CUTIE_CHECK_ARG(n >= 0, "adam_step: n < 0");
     if (n == 0) return CUTIE_OK;
@@ -195,7 +204,7 @@ extern "C" int cutie_adam_step(float* p, const float* g, float* m, float* v, int
     int64_t grid = cutie::cdiv(n, 256);
     if (grid > 4096) grid = 4096;
     hipLaunchKernelGGL(adam_kernel, dim3((int)grid), dim3(256), 0, stream, p, g, m, v, n, lr_t, beta1, beta2, eps,
-                       gnorm_sq, clip, grad_scale);
+                       gnorm_sq, clip, grad_scale, t, loss_scale);
     CUTIE_CHECK_LAUNCH();
     return CUTIE_OK;
 }

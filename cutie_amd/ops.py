@@ -369,9 +369,11 @@ def loss_scale_update(state, gnorm_sq, backoff=0.5, growth=2.0, interval=1000, m
          float(min_scale), float(max_scale), stream())
 
 
-def adam_step(p, g, m, v, lr_t, beta1, beta2, eps, gnorm_sq, clip, grad_scale=1.0):
+def adam_step(p, g, m, v, lr_t, beta1, beta2, eps, gnorm_sq, clip, grad_scale=1.0, t=0, loss_scale=None):
+    """t, loss_scale: the caller's step count behind lr_t and the loss-scale state - with both, the kernel re-bases the
+    bias correction to the steps the device did not skip (an f16 overflow skips a step without the host knowing)"""
     call("cutie_adam_step", ptr(p), ptr(g), ptr(m), ptr(v), p.numel(), float(lr_t), float(beta1), float(beta2),
-         float(eps), ptr(gnorm_sq), float(clip), float(grad_scale), stream())
+         float(eps), ptr(gnorm_sq), float(clip), float(grad_scale), int(t), ptr(loss_scale), stream())
 
 
 def batch_scatter_add(dout, idx, dfeat):
@@ -384,11 +386,12 @@ def batch_scatter_add(dout, idx, dfeat):
     return dfeat
 
 
-def batch_gather(feat, idx, out):
-    """feat [B, n_src, C]; idx int32 [B, n_cells]; out [B, n_cells, >=C] view."""
+def batch_gather(feat, idx, out, oob=None):
+    """feat [B, n_src, C]; idx int32 [B, n_cells]; out [B, n_cells, >=C] view; oob int32 [1] counter of indices
+    outside [0, n_src) (they are clamped; tf.batch_gather raises)."""
     B, n_src, C = feat.shape
     call("cutie_batch_gather", ptr(feat), ld_of(feat), n_src, ptr(idx), idx.shape[1], B, C, ptr(out), ld_of(out),
-         dt_of(feat), stream())
+         dt_of(feat), ptr(oob), stream())
     return out
 
 

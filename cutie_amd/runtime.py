@@ -37,7 +37,7 @@ class _Plan(object):
 
 
 class Engine(object):
-    def __init__(self, network, device="cuda:0", dtype="f16", seed=0, loss_scale=None, overlap_wgrad=None):
+    def __init__(self, network, device="cuda:0", dtype="f16", seed=0, loss_scale=None, overlap_wgrad=None, max_plans=4):
         """dtype: 'f16' (the headline path: IEEE half activations and MFMA operands, f32 accumulation, statistics
         and parameters; meets the 2e-2 logit tolerance; backward runs under a dynamic loss scale kept on the device,
         initial value `loss_scale`, default 4096), 'bf16' (same tiles and MFMA rate, 8 significant bits: outside the
@@ -65,7 +65,11 @@ class Engine(object):
         self.overlap_wgrad = bool(overlap_wgrad)
         self._side = None
         self.C = network.num_classes
-        self._plans = {}
+        # buffer sets per (B, H, W, Hi), least recently used first.  The reference's loader draws a new grid shape for
+        # almost every training batch (data_loader_json.py:660-694: max over the documents plus |N(0,16)| padding), and
+        # one set is ~4 GB at B = 32, 64 x 64: only the `max_plans` most recently used shapes keep theirs.
+        self._plans = OrderedDict()
+        self.max_plans = max(1, int(max_plans))
         self._layout_params()
         self.initialize(seed)
 
@@ -142,7 +146,10 @@ class Engine(object):
     def _plan(self, B, H, W, Hi):
         key = (B, H, W, Hi)
         if key in self._plans:
+            self._plans.move_to_end(key)
             return self._plans[key]
+        while len(self._plans) >= self.max_plans:
+            self._plans.popitem(last=False)      # its tensors go back to the allocator once the caller drops the plan too
         net, dev, tdt = self.net, self.dev, self.tdt
         P = _Plan()
         P.key, P.B, P.H, P.W, P.Hi = key, B, H, W, Hi
@@ -207,8 +214,8 @@ class Engine(object):
         pooled = [n.inputs[0].channels for n in nodes if n.op == "global_pool"]
         P.pool_scratch = (torch.zeros(B * capi.POOL_TILES * max(pooled) * 2, dtype=torch.float32, device=dev)
                           if pooled else None)
-        P.counters = torch.zeros(2, dtype=torch.int32, device=dev)     # one fill per forward clears both
-        P.oob, P.bad = P.counters[0:1], P.counters[1:2]
+        P.counters = torch.zeros(3, dtype=torch.int32, device=dev)     # one fill per forward clears all
+        P.oob, P.bad, P.ps_oob = P.counters[0:1], P.counters[1:2], P.counters[2:3]
         N = B * H * W
         P.N = N
         P.ce = torch.zeros(N, dtype=torch.float32, device=dev)
@@ -285,7 +292,12 @@ class Engine(object):
                             break
                         o += i.channels
                     walk(c.name, off + o)
-                elif c.op in ("global_pool", "softmax", "positional_sampling"):
+                elif c.op == "global_pool":
+                    # dropping this gradient is exact only behind an instance norm ('global pool gradient')
+                    if self.net.layers[nm].op != "conv":
+                        raise NotImplementedError("gradient of global_pool(%s): the pooled tensor is not the output of an "
+                                                  "instance-normalised conv, so the pool's gradient does not vanish" % nm)
+                elif c.op in ("softmax", "positional_sampling"):
                     pass        # sampler: its scatter-add is added by loss_backward (_sampler_consumers)
                 else:
                     raise NotImplementedError("gradient through %s (%s)" % (c.name, c.op))
@@ -373,7 +385,8 @@ class Engine(object):
                                  fv.as_strided((B, Hi * W, feat.channels), (fv.stride(0), fv.stride(2), 1)),
                                  P.ps, P.view(n.name, n.channels).as_strided(
                                      (B, H * W, n.channels),
-                                     (P.view(n.name, n.channels).stride(0), P.view(n.name, n.channels).stride(2), 1)))
+                                     (P.view(n.name, n.channels).stride(0), P.view(n.name, n.channels).stride(2), 1)),
+                                 oob=P.ps_oob)
             elif n.op == "softmax":
                 src = n.inputs[0]
                 lab = P.labels if labels is not None else P.zero_labels
@@ -394,7 +407,11 @@ class Engine(object):
 
     def check_inputs(self, P):
         """Host-side validation of the counters the kernels keep (one sync)."""
-        oob, bad = int(P.oob.item()), int(P.bad.item()) if P.has_labels else 0
+        cnt = P.counters.cpu()
+        oob, bad, ps_oob = int(cnt[0]), int(cnt[1]) if P.has_labels else 0, int(cnt[2])
+        if ps_oob:
+            raise CutieError("%d ps_1d_indices fall outside the image feature map (tf.batch_gather raises, "
+                             "model_framework.py:83)" % ps_oob)
         late = sum(int(s[0].item()) for s in P.sync.values()) if P.bwd_ready else 0
         if late:
             raise CutieError("%d conv tiles gave up waiting for their sample's other tiles (the GPU could not hold a "

@@ -60,8 +60,10 @@ class Trainer(object):
         gn = eng.global_norm_sq(P, tf_indexed_slices=(self.world == 1))
         self.t += 1
         lr_t = self.lr * math.sqrt(1.0 - self.b2 ** self.t) / (1.0 - self.b1 ** self.t)
+        # the host's t runs ahead of m and v by the steps the device skipped on an f16 overflow: the kernel takes
+        # them out of the bias correction (loss-scale state[3]); no host read-back
         ops.adam_step(eng.params_flat, eng.grads_flat, self.m, self.v, lr_t, self.b1, self.b2, self.eps, gn,
-                      self.clip, grad_scale=1.0 / self.world)
+                      self.clip, grad_scale=1.0 / self.world, t=self.t, loss_scale=eng.loss_scale)
         if eng.loss_scale is not None:
             # f16: an overflowed backward made gn non-finite and Adam left everything untouched; halve
             # the scale then, double it after a run of good steps - on the device, nobody waits

@@ -322,7 +322,8 @@ int cutie_ghm_weights(const void* logits, int ld, int dtype, const int32_t* labe
  * adam:  scale = clip / max(sqrt(*gnorm_sq), clip);  g' = g*scale;
  *        m = b1*m + (1-b1)*g';  v = b2*v + (1-b2)*g'^2;  p -= lr_t * m / (sqrt(v) + eps)
  *        with lr_t = lr*sqrt(1-b2^t)/(1-b1^t) computed by the caller (TF's form).
- *        A non-finite *gnorm_sq leaves p, m and v untouched (the step is skipped).
+ *        A non-finite *gnorm_sq leaves p, m and v untouched (the step is skipped); with `loss_scale` and t > 0 the
+ *        bias correction then follows the number of steps that were NOT skipped (state[3] counts the skipped ones).
  *
  * Loss scale (no counterpart in the reference, which trains in f32; it is what lets the CUTIE_F16
  * path keep the gradients the reference computes instead of flushing them to zero): a device
@@ -344,12 +345,16 @@ int cutie_loss_scale_update(float* state, const float* gnorm_sq, float backoff, 
                             int interval, float min_scale, float max_scale, cutie_stream_t stream);
 int cutie_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr_t,
                     float beta1, float beta2, float eps, const float* gnorm_sq, float clip,
-                    float grad_scale, cutie_stream_t stream);
+                    float grad_scale, int t /* the caller's step count behind lr_t; 0 = take lr_t as it is */,
+                    const float* loss_scale /* nullable: lr_t is re-based to step t - (steps the device skipped) */,
+                    cutie_stream_t stream);
 
 /* K13  Model.positional_sampling, model_framework.py:73-86 (tf.batch_gather):
- * out[b, cell, :] = feat[b, idx[b, cell], :], idx clamped to [0, n_src). */
+ * out[b, cell, :] = feat[b, idx[b, cell], :].  An index outside [0, n_src) is clamped into it and bumps *oob_count
+ * (int32, nullable, caller-zeroed): tf.batch_gather raises on such an index, the caller raises from the counter. */
 int cutie_batch_gather(const void* feat, int ld_feat, int n_src, const int32_t* idx, int n_cells,
-                       int B, int C, void* out, int ld_out, int dtype, cutie_stream_t stream);
+                       int B, int C, void* out, int ld_out, int dtype, int32_t* oob_count,
+                       cutie_stream_t stream);
 
 /* backward of K13 (the gradient tf.gradients derives for tf.batch_gather):
  * dfeat[b, idx[b, cell], :] += dout[b, cell, :], idx clamped as in the forward; dfeat is a dense

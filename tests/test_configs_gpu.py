@@ -1,0 +1,138 @@
+"""BASELINE.json configs[3], configs[4] and configs[0] at their FULL shapes, on the GPU:
+
+  * CUTIE2-ASPP (model_cutie2_aspp.py:36-107), grid 128 x 64, vocabulary table 28790 = max(20000, len(dict/40000))
+    rows (main_train_json.py:135), C = 9, B = 32: sample independence bit for bit against a batch of 2, documents
+    0-1 against the float64 oracle (f32 path 1e-4; f16 headline path 2e-2), moments 0 / 1 of a normalised layer,
+    and the vocabulary hole of SURVEY.md 0.7 - id 28790 is out of range and must be counted, not gathered;
+  * CUTIE2-dilate (model_cutie2_dilate.py:36-93), grid 256 x 128, B = 1: f32 logits of one document against the
+    oracle - every tap of the dilation-16 image layer and of the trunk has an in-bounds partner at this size,
+    which the 48 x 32 case of test_model_gpu.py never exercises - and one f16 train step;
+  * configs[0] end to end is in tests/test_data_loader.py (it needs that file's loader fixtures).
+
+The model oracle is PARITY UNPINNED against TensorFlow (oracle/cutie_oracle.py header).
+"""
+import types
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import cutie2_oracle as c2  # noqa: E402
+from oracle import cutie_oracle as co  # noqa: E402
+
+DEV = "cuda:0"
+E = 128
+
+
+def _ns(B):
+    return types.SimpleNamespace(embedding_size=E, weight_decay=5e-4, hard_negative_ratio=3, batch_size=B)
+
+
+def _inputs(B, H, W, Hi, V, C, seed):
+    g = torch.Generator().manual_seed(seed)
+    grid = torch.zeros((B, H, W), dtype=torch.int64)
+    occ = torch.rand((B, H, W), generator=g) < 0.08
+    ids = torch.randint(2, V, (B, H, W), generator=g)
+    ids[torch.rand((B, H, W), generator=g) < 0.35] = 1
+    grid[occ] = ids[occ]
+    labels = torch.zeros((B, H, W), dtype=torch.int64)
+    fg = occ & (torch.rand((B, H, W), generator=g) < 0.25)
+    labels[fg] = torch.randint(1, C, (int(fg.sum()),), generator=g)
+    image = torch.rand((B, Hi, W, 3), generator=g) - 0.5                 # U(-0.5, 0.5)
+    ps = torch.randint(0, Hi * W - 1, (B, H * W), generator=g)           # U{0 .. Hi*W - 2}
+    return grid, labels, image, ps
+
+
+def test_cutie2_aspp_full_shape_128x64_vocab_28790():
+    from cutie_amd.capi import CutieError
+    from cutie_amd.model_cutie2_aspp import CUTIE2
+    from cutie_amd.runtime import Engine
+    V, C, B, H, W, Hi = 28790, 9, 32, 128, 64, 128
+    graph = c2.GRAPHS["aspp"]
+    grid, labels, image, ps = _inputs(B, H, W, Hi, V, C, 21)
+    params = c2.init_params(graph, V, E, C, seed=4)
+    ref = c2.forward(graph, params, grid[:2], image[:2].double(), ps[:2])
+    net = CUTIE2(V, C, _ns(B))
+    net.build_loss()
+    for dtype, tol in (("f32", 1e-4), ("f16", 2e-2)):
+        eng = Engine(net, DEV, dtype=dtype, max_plans=2)
+        eng.load_params(params)
+        P = eng.forward(grid.unsqueeze(-1), image=image, ps_1d_indices=ps, labels=labels)
+        eng.check_inputs(P)
+        logits32 = eng.get(P, "cls_logits")[..., :C].clone()
+        y = eng.get(P, "encoder1_4").double()
+        assert float(y.mean(dim=(1, 2)).abs().max()) < (1e-4 if dtype == "f32" else 3e-3)
+        var = y.var(dim=(1, 2), unbiased=False)
+        live = var > 1e-3
+        assert float((var[live] - 1).abs().max()) < (2e-3 if dtype == "f32" else 1e-2)
+        del y, var
+        P2 = eng.forward(grid[:2].unsqueeze(-1), image=image[:2], ps_1d_indices=ps[:2], labels=labels[:2])
+        logits2 = eng.get(P2, "cls_logits")[..., :C]
+        assert torch.equal(logits2, logits32[:2])                 # instance norm is per sample: bit for bit
+        r = ref["cls_logits"]
+        d = logits2.double().cpu() - r
+        err_l2, err_max = float(d.norm() / r.norm()), float(d.abs().max() / r.abs().max())
+        print("CUTIE2-ASPP 128x64 V=28790 %s: logits rel-L2 %.2e, max-norm %.2e" % (dtype, err_l2, err_max))
+        assert err_l2 < tol and err_max < (tol if dtype == "f32" else 2 * tol)
+        if dtype == "f32":
+            agree = float((logits2.argmax(-1).cpu() == r.argmax(-1)).double().mean())
+            assert agree >= 0.999
+            # the vocabulary hole: dict/40000 hands out index 28790, the table has rows 0 .. 28789
+            bad = grid[:2].clone()
+            bad[0, 3, 5] = V
+            bad[1, 100, 60] = V
+            Pb = eng.forward(bad.unsqueeze(-1), image=image[:2], ps_1d_indices=ps[:2])
+            assert int(Pb.oob.item()) == 2
+            with pytest.raises(CutieError, match="vocabulary"):
+                eng.check_inputs(Pb)
+            assert float(eng.get(Pb, "embedding")[0, 3, 5].abs().max()) == 0.0      # a zero row, not a stray read
+            # a sampler index outside the image feature map is counted too (tf.batch_gather raises)
+            psb = ps[:2].clone()
+            psb[1, 7] = Hi * W + 3
+            Pb = eng.forward(grid[:2].unsqueeze(-1), image=image[:2], ps_1d_indices=psb)
+            with pytest.raises(CutieError, match="ps_1d_indices"):
+                eng.check_inputs(Pb)
+        del eng, P, P2
+        torch.cuda.empty_cache()
+
+
+def test_cutie2_dilate_full_shape_256x128():
+    from cutie_amd.model_cutie2_dilate import CUTIE2
+    from cutie_amd.runtime import Engine
+    from cutie_amd.train import Trainer
+    V, C, B, H, W, Hi = 600, 9, 1, 256, 128, 256
+    graph = c2.GRAPHS["dilate"]
+    grid, labels, image, ps = _inputs(B, H, W, Hi, V, C, 22)
+    params = c2.init_params(graph, V, E, C, seed=5)
+    ref = c2.forward(graph, params, grid, image.double(), ps)
+    net = CUTIE2(V, C, _ns(B))
+    net.build_loss()
+    eng = Engine(net, DEV, dtype="f32", max_plans=1)
+    eng.load_params(params)
+    P = eng.forward(grid.unsqueeze(-1), image=image, ps_1d_indices=ps, labels=labels)
+    eng.check_inputs(P)
+    for name in ("image_encoder1_8", "feature_fuser", "encoder1_8", "cls_logits"):
+        got = eng.get(P, name)[..., :ref[name].shape[-1]].double().cpu()
+        err = float((got - ref[name]).abs().max() / ref[name].abs().max())
+        print("CUTIE2-dilate 256x128 f32 %s: %.2e" % (name, err))
+        assert err < 1e-4, name
+    agree = float((eng.get(P, "softmax").cpu().argmax(-1) == ref["softmax"].argmax(-1)).double().mean())
+    assert agree >= 0.999
+    del eng, P
+    torch.cuda.empty_cache()
+    eng = Engine(net, DEV, dtype="f16", max_plans=1)
+    eng.load_params(params)
+    P = eng.forward(grid.unsqueeze(-1), image=image, ps_1d_indices=ps, labels=labels)
+    r = ref["cls_logits"]
+    d = eng.get(P, "cls_logits")[..., :C].double().cpu() - r
+    print("CUTIE2-dilate 256x128 f16: logits rel-L2 %.2e" % float(d.norm() / r.norm()))
+    assert float(d.norm() / r.norm()) < 2e-2
+    before = eng.params_flat.clone()
+    out = Trainer(eng, learning_rate=1e-4, check_inputs=True).step(
+        {"grid_table": grid.unsqueeze(-1), "gt_classes": labels, "data_image": image, "ps_1d_indices": ps})
+    assert np.isfinite(out["total_loss"]) and np.isfinite(out["global_norm"]) and out["global_norm"] > 0
+    move = (eng.params_flat - before).abs()
+    assert 0 < float(move.max()) <= 1.01e-4
+    eng.check_inputs(P)                                           # no conv tile gave up waiting for its sample

@@ -809,6 +809,15 @@ def test_loss_scale_state_machine(ops):
         nbad = torch.full((1,), bad, dtype=torch.float32, device=DEV)
         ops.adam_step(p2, g2, m2, v2, 1e-3, 0.9, 0.999, 1e-8, nbad, 10.0)
         assert torch.equal(p2, p) and torch.equal(m2, m) and torch.equal(v2, v)
+    # bias correction after skipped steps: the caller's t = 5 with 3 steps skipped is Adam's step 2
+    import math
+    c = lambda t: math.sqrt(1 - 0.999 ** t) / (1 - 0.9 ** t)
+    skipped = torch.tensor([1024.0, 1 / 1024.0, 0.0, 3.0], device=DEV)
+    pa, ma, va = w.clone(), m.clone(), v.clone()
+    pb, mb, vb = w.clone(), m.clone(), v.clone()
+    ops.adam_step(pa, g2, ma, va, 1e-3 * c(5), 0.9, 0.999, 1e-8, nsq, 10.0, t=5, loss_scale=skipped)
+    ops.adam_step(pb, g2, mb, vb, 1e-3 * c(2), 0.9, 0.999, 1e-8, nsq, 10.0)
+    assert relerr(pa - w, pb - w) < 5e-4 and torch.equal(ma, mb)      # the moves are ~1e-3 of f32 values ~1
     # the scale itself
     ninf = torch.full((1,), float("inf"), dtype=torch.float32, device=DEV)
     ops.loss_scale_update(ls, ninf, interval=3)

@@ -203,6 +203,35 @@ def test_shapes_other_than_64(oracle_run):
         assert rel(eng.get(P, "softmax"), L["softmax"]) < 1e-4
 
 
+def test_plan_cache_is_bounded_over_many_grid_shapes(oracle_run):
+    """The reference's loader draws a new (rows, cols) for almost every training batch (data_loader_json.py:660-694);
+    the engine keeps buffer sets for the `max_plans` most recently used shapes only."""
+    from cutie_amd.model_cutie_aspp import CUTIERes
+    from cutie_amd.runtime import Engine
+    from cutie_amd.train import Trainer
+    net = CUTIERes(V, C, params_ns())
+    net.build_loss()
+    eng = Engine(net, DEV, dtype="f16", max_plans=3)
+    tr = Trainer(eng)
+    g = torch.Generator().manual_seed(1)
+    peak = []
+    shapes = [(int(torch.randint(42, 81, (1,), generator=g)), int(torch.randint(63, 81, (1,), generator=g))) for _ in range(20)]
+    for k, (H, W) in enumerate(shapes):
+        grid, labels = make_inputs(2, H, W, 100 + k)
+        out = tr.step({"grid_table": grid.unsqueeze(-1), "gt_classes": labels})
+        assert np.isfinite(out["total_loss"])
+        torch.cuda.synchronize()
+        peak.append(torch.cuda.memory_allocated())
+        assert len(eng._plans) <= 3
+    # after the cache has filled, memory stays level: the 20th shape needs no more than the worst three of them
+    assert max(peak[3:]) <= 1.6 * max(peak[:3]), (peak[:3], max(peak))
+    # a shape seen again while still cached reuses its plan
+    P = eng._plans[next(reversed(eng._plans))]
+    H, W = shapes[-1]
+    grid, labels = make_inputs(2, H, W, 7)
+    assert eng.forward(grid.unsqueeze(-1), labels=labels) is P
+
+
 # ------------------------------------------------------------------------------ CUTIE2 (configs 4 / 5): forward
 @pytest.mark.parametrize("variant,B,H,W,Hi", [("aspp", 2, 32, 48, 40), ("dilate", 1, 48, 32, 56)])
 @pytest.mark.parametrize("dtype", ["f32", "f16", "bf16"])
