@@ -110,6 +110,33 @@ class _Prefetcher(object):
         self._t.join(timeout=5.0)
 
 
+_FRONT = None      # per worker process: (loader clone, update_dict)
+
+
+def _front_init(state, known_words, update_dict):
+    """worker set-up: a DataLoader clone that holds only what _collect_label / _collect_data read; its dictionary
+    starts with the parent's words at count 0 so that what a file adds can be told apart"""
+    global _FRONT
+    clone = object.__new__(DataLoader)
+    clone.__dict__.update(state)
+    clone.dictionary = dict.fromkeys(known_words, 0)
+    _FRONT = (clone, update_dict)
+
+
+def _front_file(path):
+    """one file in a worker -> (label, item lists, word count deltas, words new to the parent in first-use order)"""
+    clone, update_dict = _FRONT
+    n_before = len(clone.dictionary)
+    label, docs = clone._load_file(path, update_dict)
+    counts = {}
+    for w, c in clone.dictionary.items():
+        if c:
+            counts[w] = c
+            clone.dictionary[w] = 0
+    new_words = list(clone.dictionary)[n_before:]      # _dress_text appended them in first-use order (dicts keep it)
+    return label, docs, counts, new_words
+
+
 class DataLoader(object):
     """grid tables producer (reference: data_loader_json.py:34)"""
 
@@ -168,6 +195,7 @@ class DataLoader(object):
         self.batch_size = _opt(params, 'batch_size', 1)
         self.special_dict = {'*', '='}
         self.image_reader = _opt(params, 'image_reader', None)   # callable(path) -> HxWx3 array or None
+        self.load_workers = _opt(params, 'load_workers', None)   # processes for the load-time front half; None = auto
 
         self.training_doc_files = self._get_filenames(self.doc_path)
         self.training_docs, self.training_labels = self.load_data(self.training_doc_files, update_dict=update_dict)
@@ -506,21 +534,68 @@ class DataLoader(object):
         return images, ps_1d_indices
 
     # ------------------------------------------------------------------ a1: load-time preparation
+    def _load_file(self, file, update_dict):
+        """one document file -> (label dict or None, list of item lists): the per-file body of :632-658"""
+        with open(file, encoding='utf-8') as f:
+            data = json.load(f)
+        file_id = data['global_attributes']['file_id']
+        label = self._collect_label(file_id, data['fields'])
+        if not label:            # corrupted sample
+            return None, []
+        return label, self._collect_data(file_id, data['text_boxes'], update_dict)
+
     def load_data(self, data_files, update_dict=False):
-        """:632-658"""
+        """:632-658.  The reference walks the files one by one; here the per-file work (JSON parse, WordPiece,
+        the natural-shape search of _collect_data) goes to `load_workers` processes when there are enough files,
+        and the results are merged in FILE ORDER, dictionary counts and new words included, so the outcome is the
+        serial one (tests/test_data_loader.py pins both against the reference's own items)."""
         label_dressed, doc_dressed = {}, []
         if not data_files:
             self._say("no data file found.")
-        for file in data_files:
-            with open(file, encoding='utf-8') as f:
-                data = json.load(f)
-            file_id = data['global_attributes']['file_id']
-            label = self._collect_label(file_id, data['fields'])
-            if not label:            # corrupted sample
-                continue
-            label_dressed.update(label)
-            doc_dressed.extend(self._collect_data(file_id, data['text_boxes'], update_dict))
+        workers = self._pool_size(len(data_files))
+        if workers <= 1:
+            for file in data_files:
+                label, docs = self._load_file(file, update_dict)
+                if label:
+                    label_dressed.update(label)
+                    doc_dressed.extend(docs)
+            return doc_dressed, label_dressed
+        import multiprocessing as mp
+        state = {k: v for k, v in self.__dict__.items() if k not in ('_tls', '_pack_cache', 'image_reader', 'dictionary')}
+        known = list(self.dictionary)
+        chunk = max(1, len(data_files) // (workers * 8))
+        with mp.get_context('spawn').Pool(workers, initializer=_front_init, initargs=(state, known, update_dict)) as pool:
+            for label, docs, counts, new_words in pool.imap(_front_file, data_files, chunksize=chunk):
+                for w in new_words:                      # first report in file order = the serial insertion order
+                    if w not in self.dictionary:
+                        self.dictionary[w] = 0
+                for w, c in counts.items():
+                    self.dictionary[w] += c
+                if label:
+                    label_dressed.update(label)
+                    doc_dressed.extend(docs)
         return doc_dressed, label_dressed
+
+    def _pool_size(self, n_files):
+        """worker processes for load_data: params.load_workers (0 / 1 = serial); by default one per host core (at most
+        16) once there are 64 files or more - never from a process that has already initialised the GPU (its children
+        would be spawned from a GPU process)."""
+        want = self.load_workers
+        import sys
+        main = sys.modules.get('__main__')
+        if getattr(main, '__file__', None) is None and getattr(main, '__spec__', None) is None:
+            return 1        # stdin / interactive: spawned workers cannot re-import __main__ (the pool would respawn them for ever)
+        if want is None:
+            if n_files < 64:
+                return 1
+            try:
+                import torch
+                if torch.cuda.is_initialized():
+                    return 1
+            except ImportError:
+                pass
+            want = min(16, os.cpu_count() or 1)
+        return max(1, min(int(want), n_files))
 
     def _cal_rows_cols(self, docs, extra_augmentation=False, dropout=False):
         """:660-694"""

@@ -32,7 +32,7 @@ class GradBuckets(object):
 
     def __init__(self, flat, n_front, n_buckets=4, group=None, align=64):
         self.flat, self.group = flat, group
-        self._drain_first = None
+        self._checked = False
         self.n_front = int(n_front)
         step = max(align, (self.n_front // max(1, n_buckets) + align - 1) // align * align)
         self.bounds = list(range(step, self.n_front, step)) + [self.n_front]
@@ -43,13 +43,14 @@ class GradBuckets(object):
 
     def _launch(self, lo, hi):
         if hi > lo:
-            if self._drain_first is None:
-                # gloo moves device tensors through the host on its own threads and was seen to
-                # dead-lock when further kernels pile up behind an un-drained stream (two ranks
-                # sharing one GPU in the tests); RCCL enqueues on its own stream and needs nothing
-                self._drain_first = self.flat.is_cuda and dist.get_backend(self.group) == "gloo"
-            if self._drain_first:
-                torch.cuda.current_stream(self.flat.device).synchronize()
+            if not self._checked:
+                # device tensors go over RCCL only.  gloo stages them through the host on threads of its own; with two
+                # ranks on one GPU that dead-locked intermittently in round 1 and the cause was never found, so the
+                # path is gone rather than papered over: gloo is for the CPU tests (host tensors).
+                if self.flat.is_cuda and dist.get_backend(self.group) != "nccl":
+                    raise RuntimeError("GradBuckets: device gradients need the nccl (RCCL) backend, not %s"
+                                       % dist.get_backend(self.group))
+                self._checked = True
             self.works.append(dist.all_reduce(self.flat[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
     def ready(self, upto):
@@ -58,8 +59,12 @@ class GradBuckets(object):
             self._launch(self.next_lo, hi)
             self.next_lo, self.next_b = hi, self.next_b + 1
 
-    def finish(self):
+    def finish(self, extra=None):
+        """extra: a small tensor summed over the ranks along with the last slice (the embedding's share of the
+        clip norm, see Trainer.step)"""
         self._launch(self.next_lo, self.flat.numel())
+        if extra is not None:
+            self.works.append(dist.all_reduce(extra, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
         for w in self.works:
             w.wait()
         self.reset()

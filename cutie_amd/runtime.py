@@ -533,12 +533,26 @@ class Engine(object):
         P.reg_div = float(world)       # the kernel's 0.5 * (world * wd) * sum(w^2) is world times the loss term
         P.l2_pending = False
 
-    def global_norm_sq(self, P, tf_indexed_slices=True):
-        """Squared global norm.  With tf_indexed_slices (single replica, TF parity) the embedding
-        enters through its un-deduplicated per-cell rows, as tf.clip_by_global_norm does for an
-        IndexedSlices gradient; otherwise through the dense summed gradient."""
+    def embedding_rows_sumsq(self, P):
+        """sum over this replica's grid cells of |d(embedding output) row|^2, loss scale taken out: the embedding's
+        share of tf.clip_by_global_norm (IndexedSlices values, un-deduplicated).  A 1-float device tensor."""
+        if getattr(P, "emb_sq", None) is None:
+            P.emb_sq = torch.zeros(1, dtype=torch.float32, device=self.dev)
+        P.emb_sq.zero_()
+        if hasattr(P, "d_embed"):
+            ops.sumsq(P.d_embed.reshape(-1), P.emb_sq, P.scratch, self.loss_scale)     # still scaled: activation dtype
+        return P.emb_sq
+
+    def global_norm_sq(self, P, tf_indexed_slices=True, embedding_rows_sq=None):
+        """Squared global norm the way tf.clip_by_global_norm sees it: every dense gradient, and the
+        embedding through its un-deduplicated per-cell rows.  embedding_rows_sq: that share already summed over the
+        data-parallel ranks (Trainer.step); tf_indexed_slices=False takes the dense summed embedding gradient
+        instead (not TF's definition; kept for comparisons)."""
         P.gnorm_sq.zero_()
-        if tf_indexed_slices and hasattr(P, "d_embed"):
+        if embedding_rows_sq is not None:
+            ops.sumsq(self.grads_flat[:self.n_dense], P.gnorm_sq, P.scratch)
+            P.gnorm_sq.add_(embedding_rows_sq)
+        elif tf_indexed_slices and hasattr(P, "d_embed"):
             ops.sumsq(self.grads_flat[:self.n_dense], P.gnorm_sq, P.scratch)
             ops.sumsq(P.d_embed.reshape(-1), P.gnorm_sq, P.scratch, self.loss_scale)   # still scaled: activation dtype
         else:

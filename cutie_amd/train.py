@@ -7,7 +7,8 @@ learning-rate decay x0.1 every lr_decay_step iterations (:225-226).  The two par
 collapse into one step because ghm_weights is all ones when use_ghm=0 (:249-251).
 
 New: data parallelism (cutie_amd.parallel) - each rank runs the step on its shard of documents;
-hard negative mining is per replica (SURVEY.md 8e caveat).
+hard negative mining is per replica (SURVEY.md 8e caveat); the clip norm is TF's at every world size (the embedding
+enters through its per-cell rows, summed over the ranks).  The losses a rank reports are its own shard's.
 """
 import math
 import os
@@ -53,11 +54,17 @@ class Trainer(object):
             # each bucket's all-reduce starts as soon as backward has finished its slice and runs
             # on the collective's stream under the remaining layers' dgrad/wgrad kernels
             eng.loss_backward(P, on_ready=self.buckets.ready)
-            self.buckets.finish()
+            # tf.clip_by_global_norm takes the embedding gradient as IndexedSlices: one row per grid cell, NOT summed
+            # per id.  For the global batch those rows are the concatenation of every rank's rows, so
+            # their squared norm is the SUM of the ranks' local ones: one more float in the last collective, and the
+            # clip is the same function of the global batch at every world size.
+            emb_sq = eng.embedding_rows_sumsq(P)
+            self.buckets.finish(extra=emb_sq)
             eng.add_l2_after_reduce(P, self.world)     # one launch over the reduced conv range
+            gn = eng.global_norm_sq(P, embedding_rows_sq=emb_sq)
         else:
             eng.loss_backward(P)
-        gn = eng.global_norm_sq(P, tf_indexed_slices=(self.world == 1))
+            gn = eng.global_norm_sq(P)
         self.t += 1
         lr_t = self.lr * math.sqrt(1.0 - self.b2 ** self.t) / (1.0 - self.b1 ** self.t)
         # the host's t runs ahead of m and v by the steps the device skipped on an f16 overflow: the kernel takes

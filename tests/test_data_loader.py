@@ -467,3 +467,35 @@ def test_config0_invoice_to_accuracy_on_device_softmax(workdir):
             assert got[1:3] == want[1:3] and abs(got[0] - want[0]) < 1e-12 and got[3] == want[3]
         else:                                                     # a probability within rounding of the 0.5 threshold
             assert dtype != "f32" and flips <= max(2, marked // 50) and abs(got[0] - want[0]) < 0.05
+
+
+def test_load_data_process_pool_equals_serial(workdir):
+    """f3: the load-time front half (JSON parse, WordPiece, natural-shape search) on a process pool gives the serial
+    result - items, labels, dictionary counts AND the insertion order of new words (update_dict=True) - which is itself
+    pinned by the reference's own items (tests/golden/faktura1_items.json)."""
+    many = workdir / "many"
+    os.makedirs(many, exist_ok=True)
+    src = os.path.join(GOLD, "invoice", "Faktura1.pdf_0.json")
+    with open(src, encoding="utf-8") as f:
+        doc = json.load(f)
+    for k in range(12):          # distinct file ids, a few distinct new words per file
+        d = json.loads(json.dumps(doc))
+        d["global_attributes"]["file_id"] = "copy_%02d.jpg" % k
+        d["text_boxes"][3]["text"] = "zzq%dx" % (k % 5)
+        d["text_boxes"][7]["text"] = "Qq%d" % (k // 3)
+        with open(many / ("copy_%02d.json" % k), "w", encoding="utf-8") as f:
+            json.dump(d, f)
+    out = {}
+    for workers in (1, 3):
+        for update in (False, True):
+            p = make_params(workdir, doc_path=str(many), load_workers=workers, save_dict=False)
+            ld = DataLoader(p, update_dict=update, load_dictionary=True, verbose=False)
+            assert ld._pool_size(12) == workers
+            out[(workers, update)] = (ld.training_docs + ld.validation_docs, ld.training_labels, list(ld.dictionary.items()),
+                                      ld.training_doc_files)
+    for update in (False, True):
+        a, b = out[(1, update)], out[(3, update)]
+        assert a[3] == b[3]                       # same file order
+        assert a[0] == b[0] and a[1] == b[1]
+        assert a[2] == b[2], "dictionary words / counts / insertion order differ"
+    assert len(out[(3, True)][2]) > len(out[(3, False)][2])       # update_dict added the new words
