@@ -57,20 +57,20 @@ SIGNATURES = {
     "cutie_conv_stats_tiles": (_i, [_i, _i]),
     "cutie_conv_fwd": (_i, [_c.POINTER(ConvSeg), _i, _i, _i, _i, _i, _vp, _i, _i, _vp, _i, _vp, _i, _i, _vp]),
     "cutie_conv_dgrad_in_stats": (_i, [_c.POINTER(ConvSeg), _i, _i, _i, _i, _i, _vp, _i, _i, _vp, _i, _i, _vp, _i, _f, _vp,
-                                       _i, _i, _vp]),
+                                       _i, _vp, _i, _i, _vp]),
     "cutie_conv_sync_bytes": (_sz, [_i, _i]),
     "cutie_conv_dgrad_in_bwd": (_i, [_c.POINTER(ConvSeg), _i, _i, _i, _i, _i, _vp, _i, _vp, _i, _vp, _i, _f, _vp, _i, _i,
-                                     _vp, _i, _vp, _i, _vp, _sz, _i, _vp]),
+                                     _vp, _vp, _i, _vp, _i, _vp, _sz, _i, _vp]),
     "cutie_conv_wgrad_workspace_bytes": (_sz, [_i, _i, _i, _i, _i, _i, _i]),
     "cutie_conv_wgrad": (_i, [_vp, _i, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _i, _i, _vp, _sz, _vp]),
     "cutie_pack_weights": (_i, [_vp, _i, _i, _i, _vp, _i, _vp, _i, _i, _vp]),
     "cutie_pack_weights_batched": (_i, [_c.POINTER(PackDesc), _i, _i, _vp]),
     "cutie_in_tiles": (_i, [_i, _i, _i]),
-    "cutie_in_stats": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _i, _vp]),
-    "cutie_in_apply": (_i, [_vp, _i, _i, _vp, _i, _f, _vp, _i, _i, _i, _i, _i, _vp]),
-    "cutie_in_bwd_stats": (_i, [_vp, _i, _i, _vp, _i, _i, _vp, _i, _f, _vp, _i, _i, _i, _i, _vp]),
+    "cutie_in_stats": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _i, _vp, _i, _vp]),
+    "cutie_in_apply": (_i, [_vp, _i, _i, _vp, _i, _f, _vp, _i, _i, _i, _i, _i, _vp, _i, _vp]),
+    "cutie_in_bwd_stats": (_i, [_vp, _i, _i, _vp, _i, _i, _vp, _i, _f, _vp, _i, _i, _i, _i, _vp, _i, _vp]),
     "cutie_in_bwd_apply": (_i, [_vp, _i, _i, _vp, _i, _i, _vp, _i, _f, _vp, _i, _i, _vp, _i, _i, _vp, _i, _i, _i, _i,
-                                _vp]),
+                                _vp, _vp]),
     "cutie_sum_rows": (_i, [_vp, _i, _i, _vp, _i, _vp]),
     "cutie_sum_rows_batched": (_i, [_c.POINTER(SumRowsDesc), _i, _i, _i, _vp]),
     "cutie_spatial_mean_bcast": (_i, [_vp, _i, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp]),

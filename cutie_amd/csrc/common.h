@@ -105,6 +105,16 @@ __device__ __forceinline__ void store4(bf16_t* p, float4 v) {
     *reinterpret_cast<uint2*>(p) = u;
 }
 
+// Instance-norm moments are kept about a per-channel shift, (sum (x - sh), sum (x - sh)^2), with sh = act(bias[c]): a
+// channel that its bias dominates (mean >> std) would lose its whole variance in f32 E[x^2] - E[x]^2.  The shift is a
+// function of the layer's bias and activation code only, so producers and consumers compute the same value; bias
+// NULL means sh = 0 (plain sums).  mean = sh + S1/N, var = S2/N - (S1/N)^2.
+__device__ __forceinline__ float norm_shift(const float* bias, int act, int c) {
+    if (!bias) return 0.f;
+    const float b = bias[c];
+    return act == 1 ? fmaxf(b, 0.f) : (act == 2 ? 1.f / (1.f + expf(-b)) : b);
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -38,6 +38,8 @@ struct ConvParams {
     const float* bw_stats;   // [B][bw_stats_tiles][n_out][2]
     int bw_stats_tiles;
     float bw_eps;
+    const float* bw_bias;    // the forward layer's bias and activation code: the shift its moments are kept about (nullable)
+    int bw_act;
     float* bw_red;           // [B][bw_red_tiles][n_out][2]
     int bw_red_tiles;
     // Rendezvous of a sample's tiles inside such a data-gradient launch (conv_wide only, with bw_*; nullable): after

@@ -227,6 +227,7 @@ __global__ __launch_bounds__(CONV_NT, 2) void conv_kernel(ConvParams p) {
     for (int n = 0; n < 4; ++n) {
         const int col = n0 + wn * 64 + n * 16 + li;
         const float bv = (p.bias && col < n_out) ? p.bias[col] : 0.f;
+        const float sh = (p.bias && col < n_out) ? cutie::norm_shift(p.bias, p.relu, col) : 0.f;      // the moments' shift
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int m = 0; m < CONV_MB; ++m) {
@@ -238,9 +239,11 @@ __global__ __launch_bounds__(CONV_NT, 2) void conv_kernel(ConvParams p) {
                 float v = acc[m][n][r] + bv;
                 if (p.relu == 1) v = fmaxf(v, 0.f);
                 else if (p.relu == 2) v = 1.f / (1.f + expf(-v));
-                if (!(h < H && w < W)) v = 0.f;
-                s1 += v;
-                s2 += v * v;
+                const bool inside = h < H && w < W;
+                if (!inside) v = 0.f;
+                const float d = inside ? v - sh : 0.f;
+                s1 += d;
+                s2 += d * d;
                 const int ml = mb * 16 + lg * 4 + r;
                 store_from_f32(Cs + ml * 128 + wn * 64 + n * 16 + li, v);
             }
@@ -765,6 +768,8 @@ struct NormBwd {      // the reduction of cutie_in_bwd_stats, asked of a data-gr
     float eps;
     float* red;
     int red_tiles;
+    const float* bias;   // the forward layer's bias and activation code: the shift of its moments
+    int act;
     // cutie_conv_dgrad_in_bwd: the second half of the norm's gradient as well (dz, bias-gradient partials)
     void* dz;
     int ld_dz, relu;
@@ -792,7 +797,7 @@ static int conv_fwd_impl(const cutie_conv_seg* segs, int n_segs, int B, int H, i
 
     ConvParams p;
     p.nseg = n_segs;
-    p.bw_a = nullptr; p.bw_ld_a = 0; p.bw_stats = nullptr; p.bw_stats_tiles = 0; p.bw_eps = 0.f; p.bw_red = nullptr; p.bw_red_tiles = 0; p.perm_n = 0;
+    p.bw_a = nullptr; p.bw_ld_a = 0; p.bw_stats = nullptr; p.bw_stats_tiles = 0; p.bw_eps = 0.f; p.bw_bias = nullptr; p.bw_act = 0; p.bw_red = nullptr; p.bw_red_tiles = 0; p.perm_n = 0;
     p.rv_cnt = nullptr; p.rv_dz = nullptr; p.rv_ld_dz = 0; p.rv_dbias = nullptr; p.rv_dbias_tiles = 0; p.rv_relu = 0; p.rv_plain_order = 0; p.rv_err = nullptr; p.rv_nowait = 0;
     int twb, th_g;
     generic_tiling(W, th_g, twb);
@@ -855,7 +860,7 @@ static int conv_fwd_impl(const cutie_conv_seg* segs, int n_segs, int B, int H, i
             bool meet = false;
             if (fuse) {
                 q.bw_a = (const char*)nb->a; q.bw_ld_a = nb->ld_a; q.bw_stats = nb->stats; q.bw_stats_tiles = nb->stats_tiles;
-                q.bw_eps = nb->eps; q.bw_red = nb->red; q.bw_red_tiles = nb->red_tiles;
+                q.bw_eps = nb->eps; q.bw_red = nb->red; q.bw_red_tiles = nb->red_tiles; q.bw_bias = nb->bias; q.bw_act = nb->act;
                 // the whole norm gradient inside this launch: a sample's tiles meet after publishing their sums
                 int plain = 0;
                 meet = nb->dz && nb->sync && cutie::config().rendezvous && nb->relu != 2 && (nb->ld_dz * 2) % 16 == 0 &&
@@ -872,7 +877,7 @@ static int conv_fwd_impl(const cutie_conv_seg* segs, int n_segs, int B, int H, i
             if (meet) return 1;      // positive: dz and dbias are in place (callers inside this file only)
             if (fuse || !nb) return rc;
             return cutie_in_bwd_stats(out, ld_out, out_dtype, nb->a, nb->ld_a, nb->a_dtype, nb->stats, nb->stats_tiles, nb->eps,
-                                      nb->red, nb->red_tiles, B, H * W, n_out, stream_);
+                                      nb->red, nb->red_tiles, B, H * W, n_out, nb->bias, nb->act, stream_);
         }
     }
     int rc;
@@ -890,7 +895,7 @@ static int conv_fwd_impl(const cutie_conv_seg* segs, int n_segs, int B, int H, i
     if (rc != CUTIE_OK || !nb) return rc;
     // kernels without the fused reduction: the separate pass, into the same slots' array
     return cutie_in_bwd_stats(out, ld_out, out_dtype, nb->a, nb->ld_a, nb->a_dtype, nb->stats, nb->stats_tiles, nb->eps, nb->red,
-                              nb->red_tiles, B, H * W, n_out, stream_);
+                              nb->red_tiles, B, H * W, n_out, nb->bias, nb->act, stream_);
 }
 
 extern "C" int cutie_conv_fwd(const cutie_conv_seg* segs, int n_segs, int B, int H, int W, int n_out, void* out,
@@ -902,8 +907,8 @@ extern "C" int cutie_conv_fwd(const cutie_conv_seg* segs, int n_segs, int B, int
 
 extern "C" int cutie_conv_dgrad_in_stats(const cutie_conv_seg* segs, int n_segs, int B, int H, int W, int n_out, void* out,
                                          int ld_out, int out_dtype, const void* a, int ld_a, int a_dtype, const float* stats,
-                                         int stats_tiles, float eps, float* red, int red_tiles, int dtype,
-                                         cutie_stream_t stream_) {
+                                         int stats_tiles, float eps, float* red, int red_tiles,
+                                         const float* shift_bias, int shift_act, int dtype, cutie_stream_t stream_) {
     CUTIE_CHECK_ARG(B >= 0 && H >= 1 && W >= 1 && n_out >= 1, "conv_dgrad_in_stats: bad sizes");
     if (B == 0) return CUTIE_OK;
     CUTIE_CHECK_ARG(a && stats && red && ld_a >= n_out, "conv_dgrad_in_stats: null pointer or ld_a < n_out");
@@ -912,7 +917,8 @@ extern "C" int cutie_conv_dgrad_in_stats(const cutie_conv_seg* segs, int n_segs,
                     red_tiles, H, W, cutie_conv_stats_tiles(H, W));
     CUTIE_CHECK_ARG((reinterpret_cast<uintptr_t>(stats) & 7) == 0 && (reinterpret_cast<uintptr_t>(red) & 7) == 0,
                     "conv_dgrad_in_stats: stats and red must be 8-byte aligned");
-    const NormBwd nb = {a, ld_a, a_dtype, stats, stats_tiles, eps, red, red_tiles, nullptr, 0, 0, nullptr, 0, nullptr};
+    const NormBwd nb = {a, ld_a, a_dtype, stats, stats_tiles, eps, red, red_tiles, shift_bias, shift_act,
+                        nullptr, 0, 0, nullptr, 0, nullptr};
     return conv_fwd_impl(segs, n_segs, B, H, W, n_out, out, ld_out, out_dtype, nullptr, 0, nullptr, 0, dtype, &nb, stream_);
 }
 
@@ -923,8 +929,9 @@ extern "C" size_t cutie_conv_sync_bytes(int B, int n_out) {
 
 extern "C" int cutie_conv_dgrad_in_bwd(const cutie_conv_seg* segs, int n_segs, int B, int H, int W, int n_out, void* dy,
                                        int ld_dy, const void* a, int ld_a, const float* stats, int stats_tiles, float eps,
-                                       float* red, int red_tiles, int relu, void* dz, int ld_dz, float* dbias_part,
-                                       int dbias_tiles, void* sync, size_t sync_bytes, int dtype, cutie_stream_t stream_) {
+                                       float* red, int red_tiles, int relu, const float* shift_bias, void* dz, int ld_dz,
+                                       float* dbias_part, int dbias_tiles, void* sync, size_t sync_bytes, int dtype,
+                                       cutie_stream_t stream_) {
     CUTIE_CHECK_ARG(B >= 0 && H >= 1 && W >= 1 && n_out >= 1, "conv_dgrad_in_bwd: bad sizes");
     if (B == 0) return CUTIE_OK;
     CUTIE_CHECK_ARG(dy && a && stats && red && dz && ld_dy >= n_out && ld_a >= n_out && ld_dz >= n_out,
@@ -940,13 +947,13 @@ extern "C" int cutie_conv_dgrad_in_bwd(const cutie_conv_seg* segs, int n_segs, i
         cutie::set_error("conv_dgrad_in_bwd: sync area %zu < %zu bytes", sync_bytes, cutie_conv_sync_bytes(B, n_out));
         return CUTIE_E_WORKSPACE;
     }
-    const NormBwd nb = {a, ld_a, dtype, stats, stats_tiles, eps, red, red_tiles, dz, ld_dz, relu, dbias_part, dbias_tiles,
-                        (unsigned*)sync};
+    const NormBwd nb = {a, ld_a, dtype, stats, stats_tiles, eps, red, red_tiles, shift_bias, relu, dz, ld_dz, relu, dbias_part,
+                        dbias_tiles, (unsigned*)sync};
     const int rc = conv_fwd_impl(segs, n_segs, B, H, W, n_out, dy, ld_dy, dtype, nullptr, 0, nullptr, 0, dtype, &nb, stream_);
     if (rc == 1) return CUTIE_OK;      // one launch did all of it
     if (rc != CUTIE_OK) return rc;
     return cutie_in_bwd_apply(dy, ld_dy, dtype, a, ld_a, dtype, stats, stats_tiles, eps, red, red_tiles, relu, dz, ld_dz,
-                              dtype, dbias_part, dbias_tiles, B, H * W, n_out, stream_);
+                              dtype, dbias_part, dbias_tiles, B, H * W, n_out, shift_bias, stream_);
 }
 
 extern "C" size_t cutie_conv_wgrad_workspace_bytes(int B, int H, int W, int cin, int cout, int kh, int kw) {

@@ -107,9 +107,9 @@ __device__ __forceinline__ void conv_wide_epilogue(const ConvParams& p, float4_t
     float* tab = reinterpret_cast<float*>(smem + S::TAB);       // [2][BN]
     if (bw && tid < BN) {
         const float inv_n = 1.f / (float)(H * W);
-        const float mean = fs * inv_n;
-        const float var = fmaxf(fss * inv_n - mean * mean, 0.f);
-        tab[tid] = mean;
+        const float md = fs * inv_n;             // the moments are kept about act(bias): norm.hip's fold_slots<1>
+        const float var = fmaxf(fss * inv_n - md * md, 0.f);
+        tab[tid] = md + (n0 + tid < n_out ? norm_shift(p.bw_bias, p.bw_act, n0 + tid) : 0.f);
         tab[BN + tid] = rsqrtf(var + p.bw_eps);
     }
 #pragma unroll
@@ -117,6 +117,7 @@ __device__ __forceinline__ void conv_wide_epilogue(const ConvParams& p, float4_t
         const int cl = wn * 64 + n * 16 + li;
         const int col = n0 + cl;
         const float bv = (p.bias && col < n_out) ? p.bias[col] : 0.f;
+        const float sh = p.relu ? fmaxf(bv, 0.f) : bv;      // norm_shift(p.bias, p.relu, col): the moments' shift
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int m = 0; m < S::MB; ++m) {
@@ -127,9 +128,11 @@ __device__ __forceinline__ void conv_wide_epilogue(const ConvParams& p, float4_t
                 const int w = w0 + (mb % TCB) * 16 + lg * 4 + r;
                 float v = acc[m][n][r] + bv;
                 if (p.relu) v = fmaxf(v, 0.f);
-                if (!(h < H && w < W)) v = 0.f;
-                s1 += v;
-                s2 += v * v;
+                const bool inside = h < H && w < W;
+                if (!inside) v = 0.f;
+                const float d = inside ? v - sh : 0.f;
+                s1 += d;
+                s2 += d * d;
                 store_from_f32(Cs + (mb * 16 + lg * 4 + r) * BN + cl, v);
             }
         }

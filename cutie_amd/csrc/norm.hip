@@ -122,14 +122,15 @@ __device__ __forceinline__ void sum_tiles(const float* p, int b, int T, int C, i
 // MODE 0: t0 = sum0, t1 = sum1;  MODE 1: t0 = mean, t1 = 1/sigma (the arithmetic of mean_inv).
 // The caller synchronises before reading the tables.
 template <int MODE>
-__device__ __forceinline__ void fold_slots(const float* p, int b, int T, int C, float inv_n, float eps, float* t0, float* t1) {
+__device__ __forceinline__ void fold_slots(const float* p, int b, int T, int C, float inv_n, float eps, float* t0, float* t1,
+                                           const float* bias = nullptr, int act = 0) {
     for (int c = threadIdx.x; c < C; c += 256) {
         float s, ss;
         sum_tiles(p, b, T, C, c, s, ss);
         if (MODE == 1) {
-            const float mean = s * inv_n;
-            const float var = fmaxf(ss * inv_n - mean * mean, 0.f);
-            s = mean;
+            const float md = s * inv_n;          // mean of (x - shift)
+            const float var = fmaxf(ss * inv_n - md * md, 0.f);
+            s = md + norm_shift(bias, act, c);
             ss = rsqrtf(var + eps);
         }
         t0[c] = s;
@@ -153,16 +154,19 @@ __device__ __forceinline__ void block_reduce_store(float (*red)[256][VEC], const
 
 template <int VEC, typename TA>
 __global__ __launch_bounds__(256) void in_stats_kernel(const TA* __restrict__ a, int ld_a, int HW, int C,
-                                                       float* __restrict__ stats) {
+                                                       float* __restrict__ stats, const float* __restrict__ bias, int act) {
     __shared__ float red[2][256][VEC];
     const int CV = C / VEC;
     const Map m = make_map(HW, CV);
     float s[VEC] = {}, ss[VEC] = {};
     if (m.active) {
+        float sh[VEC];
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) sh[e] = norm_shift(bias, act, m.cl * VEC + e);
         for (int hw = m.hw0 + m.sub; hw < m.hw1; hw += m.rows_par) {
             const vecf<VEC> x = loadv<VEC>(a + ((int64_t)m.b * HW + hw) * ld_a + m.cl * VEC);
 #pragma unroll
-            for (int e = 0; e < VEC; ++e) { s[e] += x.v[e]; ss[e] += x.v[e] * x.v[e]; }
+            for (int e = 0; e < VEC; ++e) { const float d = x.v[e] - sh[e]; s[e] += d; ss[e] += d * d; }
         }
     }
 #pragma unroll
@@ -174,12 +178,13 @@ __global__ __launch_bounds__(256) void in_stats_kernel(const TA* __restrict__ a,
 template <int VEC, typename TA, typename TY>
 __global__ __launch_bounds__(256) void in_apply_kernel(const TA* __restrict__ a, int ld_a,
                                                        const float* __restrict__ stats, int st, float eps,
-                                                       TY* __restrict__ y, int ld_y, int HW, int C) {
+                                                       TY* __restrict__ y, int ld_y, int HW, int C,
+                                                       const float* __restrict__ bias, int act) {
     extern __shared__ float tab[];      // [2][C]
     const int CV = C / VEC;
     const Map m = make_map(HW, CV);
     const float inv_n = 1.f / (float)HW;
-    fold_slots<1>(stats, m.b, st, C, inv_n, eps, tab, tab + C);
+    fold_slots<1>(stats, m.b, st, C, inv_n, eps, tab, tab + C, bias, act);
     __syncthreads();
     if (!m.active) return;
     float mean[VEC], inv[VEC];
@@ -199,12 +204,13 @@ template <int VEC, typename TD, typename TA>
 __global__ __launch_bounds__(256) void in_bwd_stats_kernel(const TD* __restrict__ dy, int ld_dy,
                                                            const TA* __restrict__ a, int ld_a,
                                                            const float* __restrict__ stats, int st, float eps,
-                                                           float* __restrict__ redout, int HW, int C) {
+                                                           float* __restrict__ redout, int HW, int C,
+                                                           const float* __restrict__ bias, int act) {
     __shared__ float red[2][256][VEC];
     extern __shared__ float tab[];      // [2][C]
     const int CV = C / VEC;
     const Map m = make_map(HW, CV);
-    fold_slots<1>(stats, m.b, st, C, 1.f / (float)HW, eps, tab, tab + C);
+    fold_slots<1>(stats, m.b, st, C, 1.f / (float)HW, eps, tab, tab + C, bias, act);
     __syncthreads();
     float s1[VEC] = {}, s2[VEC] = {};
     if (m.active) {
@@ -235,13 +241,14 @@ __global__ __launch_bounds__(256) void in_bwd_apply_kernel(const TD* __restrict_
                                                            const float* __restrict__ stats, int st, float eps,
                                                            const float* __restrict__ redin, int rt, int relu,
                                                            TZ* __restrict__ dz, int ld_dz,
-                                                           float* __restrict__ dbias, int HW, int C) {
+                                                           float* __restrict__ dbias, int HW, int C,
+                                                           const float* __restrict__ bias) {
     __shared__ float red[1][256][VEC];
     extern __shared__ float tab[];      // [4][C]
     const int CV = C / VEC;
     const Map m = make_map(HW, CV);
     const float inv_n = 1.f / (float)HW;
-    fold_slots<1>(stats, m.b, st, C, inv_n, eps, tab, tab + C);
+    fold_slots<1>(stats, m.b, st, C, inv_n, eps, tab, tab + C, bias, relu);
     fold_slots<0>(redin, m.b, rt, C, inv_n, eps, tab + 2 * C, tab + 3 * C);
     __syncthreads();
     float sb[VEC] = {};
@@ -390,7 +397,7 @@ extern "C" int cutie_in_tiles(int B, int HW, int C) {
 }
 
 extern "C" int cutie_in_stats(const void* a, int ld_a, int a_dtype, int B, int HW, int C, float* stats, int stats_tiles,
-                              cutie_stream_t stream_) {
+                              const float* shift_bias, int shift_act, cutie_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     const int vec = pick_vec(C, {ld_a}, {a});
     if (int e = check_common("in_stats", B, HW, C, vec)) return e;
@@ -400,13 +407,14 @@ extern "C" int cutie_in_stats(const void* a, int ld_a, int a_dtype, int B, int H
     const dim3 g(stats_tiles, B);
     CUTIE_DISPATCH_DTYPE(a_dtype, ADT, NORM_DISPATCH_VEC(vec,
         hipLaunchKernelGGL((in_stats_kernel<VEC, typename elem<ADT>::type>), g, dim3(256), 0, stream,
-                           (const typename elem<ADT>::type*)a, ld_a, HW, C, stats)));
+                           (const typename elem<ADT>::type*)a, ld_a, HW, C, stats, shift_bias, shift_act)));
     CUTIE_CHECK_LAUNCH();
     return CUTIE_OK;
 }
 
 extern "C" int cutie_in_apply(const void* a, int ld_a, int a_dtype, const float* stats, int stats_tiles, float eps,
-                              void* y, int ld_y, int y_dtype, int B, int HW, int C, cutie_stream_t stream_) {
+                              void* y, int ld_y, int y_dtype, int B, int HW, int C, const float* shift_bias,
+                              int shift_act, cutie_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     const int vec = pick_vec(C, {ld_a, ld_y}, {a, y});
     if (int e = check_common("in_apply", B, HW, C, vec)) return e;
@@ -417,14 +425,14 @@ extern "C" int cutie_in_apply(const void* a, int ld_a, int a_dtype, const float*
     CUTIE_DISPATCH_DTYPE(a_dtype, ADT, CUTIE_DISPATCH_DTYPE(y_dtype, YDT, NORM_DISPATCH_VEC(vec,
         hipLaunchKernelGGL((in_apply_kernel<VEC, typename elem<ADT>::type, typename elem<YDT>::type>), g, dim3(256),
                            2 * C * sizeof(float), stream, (const typename elem<ADT>::type*)a, ld_a, stats, stats_tiles, eps,
-                           (typename elem<YDT>::type*)y, ld_y, HW, C))));
+                           (typename elem<YDT>::type*)y, ld_y, HW, C, shift_bias, shift_act))));
     CUTIE_CHECK_LAUNCH();
     return CUTIE_OK;
 }
 
 extern "C" int cutie_in_bwd_stats(const void* dy, int ld_dy, int dy_dtype, const void* a, int ld_a, int a_dtype,
                                   const float* stats, int stats_tiles, float eps, float* red, int red_tiles, int B,
-                                  int HW, int C, cutie_stream_t stream_) {
+                                  int HW, int C, const float* shift_bias, int shift_act, cutie_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     const int vec = pick_vec(C, {ld_dy, ld_a}, {dy, a});
     if (int e = check_common("in_bwd_stats", B, HW, C, vec)) return e;
@@ -435,7 +443,8 @@ extern "C" int cutie_in_bwd_stats(const void* dy, int ld_dy, int dy_dtype, const
     CUTIE_DISPATCH_DTYPE(dy_dtype, DDT, CUTIE_DISPATCH_DTYPE(a_dtype, ADT, NORM_DISPATCH_VEC(vec,
         hipLaunchKernelGGL((in_bwd_stats_kernel<VEC, typename elem<DDT>::type, typename elem<ADT>::type>), g,
                            dim3(256), 2 * C * sizeof(float), stream, (const typename elem<DDT>::type*)dy, ld_dy,
-                           (const typename elem<ADT>::type*)a, ld_a, stats, stats_tiles, eps, red, HW, C))));
+                           (const typename elem<ADT>::type*)a, ld_a, stats, stats_tiles, eps, red, HW, C, shift_bias,
+                           shift_act))));
     CUTIE_CHECK_LAUNCH();
     return CUTIE_OK;
 }
@@ -443,7 +452,7 @@ extern "C" int cutie_in_bwd_stats(const void* dy, int ld_dy, int dy_dtype, const
 extern "C" int cutie_in_bwd_apply(const void* dy, int ld_dy, int dy_dtype, const void* a, int ld_a, int a_dtype,
                                   const float* stats, int stats_tiles, float eps, const float* red, int red_tiles,
                                   int relu, void* dz, int ld_dz, int dz_dtype, float* dbias, int dbias_tiles, int B,
-                                  int HW, int C, cutie_stream_t stream_) {
+                                  int HW, int C, const float* shift_bias, cutie_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     const int vec = pick_vec(C, {ld_dy, ld_a, ld_dz}, {dy, a, dz});
     if (int e = check_common("in_bwd_apply", B, HW, C, vec)) return e;
@@ -459,7 +468,7 @@ extern "C" int cutie_in_bwd_apply(const void* dy, int ld_dy, int dy_dtype, const
                                                 typename elem<ADT>::type>), g, dim3(256), 4 * C * sizeof(float), stream,
                            (const typename elem<DDT>::type*)dy, ld_dy, (const typename elem<ADT>::type*)a, ld_a,
                            stats, stats_tiles, eps, red, red_tiles, relu, (typename elem<ADT>::type*)dz, ld_dz, dbias,
-                           HW, C))));
+                           HW, C, shift_bias))));
     CUTIE_CHECK_LAUNCH();
     return CUTIE_OK;
 }
@@ -527,7 +536,7 @@ extern "C" int cutie_spatial_mean_bcast(const void* x, int ld_x, int x_dtype, vo
         // wide grid: per-(b, c) partial sums by the instance-norm statistics pass (CUTIE_POOL_TILES
         // slices of H*W per sample, one slot each), then a store pass that adds the slots in order
         const int st = CUTIE_POOL_TILES;
-        const int rc = cutie_in_stats(x, ld_x, x_dtype, B, HW, C, scratch, st, stream_);
+        const int rc = cutie_in_stats(x, ld_x, x_dtype, B, HW, C, scratch, st, nullptr, 0, stream_);
         if (rc != CUTIE_OK) return rc;
         const int rows_par = 256 / CV;
         int rows_per_wg = rows_par * 8;

@@ -165,19 +165,20 @@ def conv_sync_bytes(B, n_out):
     return capi.lib().cutie_conv_sync_bytes(int(B), int(n_out))
 
 
-def conv_dgrad_in_bwd(segs, dy, n_out, a, stats, red, dz, dbias_part=None, relu=True, sync=None, eps=IN_EPS):
+def conv_dgrad_in_bwd(segs, dy, n_out, a, stats, red, dz, dbias_part=None, relu=True, sync=None, eps=IN_EPS, bias=None):
     """Data gradient of an instance-normalised layer and the gradient of its norm + activation in one call
     (cutie_conv_dgrad_in_bwd): segs as conv_fwd (flip=True), dy = scratch view [B,H,W,>=n_out], a / stats = the layer's
     forward activation and moments, red = f32 [B,T,n_out,2] zeroed once, dz = output view, dbias_part f32 [B*T', n_out],
     sync = int32 tensor of conv_sync_bytes(B, n_out) bytes zeroed once and dedicated to this layer and shape
-    (None: two-call form).  sync[0] counts tiles whose bounded wait ran out."""
+    (None: two-call form).  sync[0] counts tiles whose bounded wait ran out.  bias: the layer's bias - with `relu` the
+    shift its moments are kept about (None when they were produced without one)."""
     B = dy.shape[0]
     arr, dt = _seg_array(segs, dy, n_out, "conv_dgrad_in_bwd")
     if dt_of(dy) != dt or dt_of(a) != dt or dt_of(dz) != dt:
         raise capi.CutieError("conv_dgrad_in_bwd: dy, a and dz must have the segments' dtype")
     call("cutie_conv_dgrad_in_bwd", arr, len(segs), B, dy.shape[1], dy.shape[2], n_out, ptr(dy), ld_of(dy), ptr(a), ld_of(a),
          ptr(stats), _tiles(stats, B, n_out, True), eps, ptr(red), _tiles(red, B, n_out, True), ACTIVATION_CODE[relu],
-         ptr(dz), ld_of(dz), ptr(dbias_part), _tiles(dbias_part, B, n_out, False), ptr(sync),
+         ptr(bias), ptr(dz), ld_of(dz), ptr(dbias_part), _tiles(dbias_part, B, n_out, False), ptr(sync),
          sync.numel() * sync.element_size() if sync is not None else 0, dt, stream())
     return dz
 
@@ -186,8 +187,8 @@ def conv_fwd(segs, out, n_out, bias=None, relu=False, stats=None, norm_bwd=None)
     """segs: list of dict(x=[B,H,W,>=cin] view, w=packed [taps, n_rows, cin], cin, kh, kw, dil, flip,
     n_off=row offset into w).  out: [B,H,W,>=n_out] view.  stats: zeroed f32 [B, T, n_out, 2] with
     T >= conv_stats_tiles(H, W): per-tile partial moments (sum over T for the totals).
-    norm_bwd = (a, stats, red) makes this a data-gradient launch that also leaves in_bwd_stats(out, a, stats)
-    in `red` (f32 [B, T, n_out, 2], zeroed once by the caller; cutie_conv_dgrad_in_stats)."""
+    norm_bwd = (a, stats, red[, shift_bias, shift_act]) makes this a data-gradient launch that also leaves
+    in_bwd_stats(out, a, stats) in `red` (f32 [B, T, n_out, 2], zeroed once by the caller; cutie_conv_dgrad_in_stats)."""
     B, H, W = out.shape[0], out.shape[1], out.shape[2]
     arr = (ConvSeg * len(segs))()
     dt = None
@@ -216,10 +217,11 @@ def conv_fwd(segs, out, n_out, bias=None, relu=False, stats=None, norm_bwd=None)
     if norm_bwd is not None:
         if bias is not None or ACTIVATION_CODE[relu] or stats is not None:
             raise capi.CutieError("conv_fwd: norm_bwd goes with a plain data gradient (no bias / activation / stats)")
-        a, fstats, red = norm_bwd
+        a, fstats, red = norm_bwd[:3]
+        sb, sa = (norm_bwd[3], norm_bwd[4]) if len(norm_bwd) > 3 else (None, None)
         call("cutie_conv_dgrad_in_stats", arr, len(segs), B, H, W, n_out, ptr(out), ld_of(out), dt_of(out), ptr(a),
              ld_of(a), dt_of(a), ptr(fstats), _tiles(fstats, B, n_out, True), IN_EPS, ptr(red),
-             _tiles(red, B, n_out, True), dt, stream())
+             _tiles(red, B, n_out, True), ptr(sb), ACTIVATION_CODE[sa], dt, stream())
         return out
     call("cutie_conv_fwd", arr, len(segs), B, H, W, n_out, ptr(out), ld_of(out), dt_of(out), ptr(bias),
          ACTIVATION_CODE[relu], ptr(stats), _tiles(stats, B, n_out, True), dt, stream())
@@ -263,32 +265,36 @@ def in_tiles(B, HW, C):
     return capi.lib().cutie_in_tiles(int(B), int(HW), int(C))
 
 
-def in_stats(a, stats):
+# The moments in `stats` are kept about shift[c] = act(bias[c]) (include/cutie_hip.h, K6): every function below takes the
+# (bias, relu) pair the producer of `stats` used - conv_fwd uses its own bias and activation; bias=None means no shift.
+def in_stats(a, stats, bias=None, relu=None):
     B, HW, C = _bhwc(a)
-    call("cutie_in_stats", ptr(a), ld_of(a), dt_of(a), B, HW, C, ptr(stats), _tiles(stats, B, C, True), stream())
+    call("cutie_in_stats", ptr(a), ld_of(a), dt_of(a), B, HW, C, ptr(stats), _tiles(stats, B, C, True), ptr(bias),
+         ACTIVATION_CODE[relu], stream())
     return stats
 
 
-def in_apply(a, stats, y, eps=IN_EPS):
+def in_apply(a, stats, y, eps=IN_EPS, bias=None, relu=None):
     B, HW, C = _bhwc(a)
     call("cutie_in_apply", ptr(a), ld_of(a), dt_of(a), ptr(stats), _tiles(stats, B, C, True), eps, ptr(y), ld_of(y),
-         dt_of(y), B, HW, C, stream())
+         dt_of(y), B, HW, C, ptr(bias), ACTIVATION_CODE[relu], stream())
     return y
 
 
-def in_bwd_stats(dy, a, stats, red, eps=IN_EPS):
+def in_bwd_stats(dy, a, stats, red, eps=IN_EPS, bias=None, relu=None):
     B, HW, C = _bhwc(a)
     call("cutie_in_bwd_stats", ptr(dy), ld_of(dy), dt_of(dy), ptr(a), ld_of(a), dt_of(a), ptr(stats),
-         _tiles(stats, B, C, True), eps, ptr(red), _tiles(red, B, C, True), B, HW, C, stream())
+         _tiles(stats, B, C, True), eps, ptr(red), _tiles(red, B, C, True), B, HW, C, ptr(bias), ACTIVATION_CODE[relu],
+         stream())
     return red
 
 
-def in_bwd_apply(dy, a, stats, red, dz, dbias_part=None, relu=True, eps=IN_EPS):
+def in_bwd_apply(dy, a, stats, red, dz, dbias_part=None, relu=True, eps=IN_EPS, bias=None):
     """dbias_part: f32 [B * T, C] partial sums, one row per (sample, slice of H*W) (fold with sum_rows)."""
     B, HW, C = _bhwc(a)
     call("cutie_in_bwd_apply", ptr(dy), ld_of(dy), dt_of(dy), ptr(a), ld_of(a), dt_of(a), ptr(stats),
          _tiles(stats, B, C, True), eps, ptr(red), _tiles(red, B, C, True), ACTIVATION_CODE[relu], ptr(dz), ld_of(dz),
-         dt_of(dz), ptr(dbias_part), _tiles(dbias_part, B, C, False), B, HW, C, stream())
+         dt_of(dz), ptr(dbias_part), _tiles(dbias_part, B, C, False), B, HW, C, ptr(bias), stream())
     return dz
 
 

@@ -330,7 +330,7 @@ class Engine(object):
                 ops.conv_dgrad_in_bwd(segs, P.dy[n.name][..., :n.channels], n.channels, P.a[n.name][..., :n.channels],
                                       P.stats[n.name], P.red[n.name], P.dz[n.name][..., :n.channels],
                                       dbias_part=P.dbpart[n.name], relu=n.attrs.get("activation", "relu"),
-                                      sync=P.sync[n.name])
+                                      sync=P.sync[n.name], bias=self.params[n.name + "/biases"])
                 return True
             ops.conv_fwd(segs, P.dy[n.name], n.channels)
         return False
@@ -370,7 +370,8 @@ class Engine(object):
                                    kh=a["kh"], kw=a["kw"], dil=a["rate"])],
                              P.a[n.name], n.channels, bias=self.params[n.name + "/biases"],
                              relu=a.get("activation", "relu"), stats=P.stats[n.name])
-                ops.in_apply(P.a[n.name][..., :n.channels], P.stats[n.name], P.view(n.name, n.channels))
+                ops.in_apply(P.a[n.name][..., :n.channels], P.stats[n.name], P.view(n.name, n.channels),
+                             bias=self.params[n.name + "/biases"], relu=a.get("activation", "relu"))
             elif n.op == "global_pool":
                 src = n.inputs[0]
                 ops.spatial_mean_bcast(P.view(src.name, src.channels), P.view(n.name, n.channels), P.pool_scratch)
@@ -475,9 +476,10 @@ class Engine(object):
                 if not have_dz:
                     dy = P.dy[n.name][..., :n.channels]
                     av = P.a[n.name][..., :n.channels]
-                    ops.in_bwd_stats(dy, av, P.stats[n.name], P.red[n.name])
+                    bias, act = self.params[n.name + "/biases"], a.get("activation", "relu")
+                    ops.in_bwd_stats(dy, av, P.stats[n.name], P.red[n.name], bias=bias, relu=act)
                     ops.in_bwd_apply(dy, av, P.stats[n.name], P.red[n.name], P.dz[n.name][..., :n.channels],
-                                     dbias_part=P.dbpart[n.name], relu=a.get("activation", "relu"))
+                                     dbias_part=P.dbpart[n.name], relu=act, bias=bias)
                 src = n.inputs[0]
                 if side is not None:
                     # dz of this layer is final: its weight gradient (and, data-parallel, the L2 term and the

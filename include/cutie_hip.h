@@ -110,7 +110,9 @@ int cutie_embed_bwd(const int32_t* ids, int64_t n_cells, const void* dout, int l
  * layer's output gradient and weights packed [tap][cin][cout]).  Several segments give the
  * gradient of a tensor with several consumers in one pass (no read-modify-write).
  * stats (nullable) f32 [B][stats_tiles][n_out][2]: per 256-pixel tile, the sum and sum of squares
- * of the values stored - the instance-norm moments of model_framework.py:423 as partial sums.
+ * of (value stored - shift), shift[n] = act(bias[n]) (0 without a bias) - the instance-norm moments of
+ * model_framework.py:423 as partial sums about the shift of K6 below; hand the same bias and activation
+ * code to whoever consumes them.
  * Tile t of a sample STORES slot t (no float atomics: reruns are bit-identical); slots the launch
  * does not own are left alone, so the caller zeroes the array ONCE, when it allocates it (every later
  * launch of the same shape stores the same slots again).  stats_tiles
@@ -150,6 +152,7 @@ int cutie_conv_dgrad_in_stats(const cutie_conv_seg* segs /* host */, int n_segs,
                               const void* a, int ld_a, int a_dtype,
                               const float* stats, int stats_tiles, float eps,
                               float* red, int red_tiles,
+                              const float* shift_bias, int shift_act /* the shift of `stats`, see K6 */,
                               int dtype, cutie_stream_t stream);
 
 /* The data gradient of such a layer AND the whole gradient of its instance norm and activation, i.e.
@@ -173,6 +176,7 @@ int cutie_conv_dgrad_in_bwd(const cutie_conv_seg* segs /* host */, int n_segs,
                             void* dy, int ld_dy,
                             const void* a, int ld_a, const float* stats, int stats_tiles, float eps,
                             float* red, int red_tiles, int relu,
+                            const float* shift_bias /* with `relu`: the shift of `stats`, see K6 */,
                             void* dz, int ld_dz, float* dbias_part, int dbias_tiles,
                             void* sync, size_t sync_bytes,
                             int dtype, cutie_stream_t stream);
@@ -208,8 +212,13 @@ int cutie_pack_weights_batched(const cutie_pack_desc* descs, int n, int dtype, c
 /* ---------------------------------------------------------------------------------------
  * K6  instance norm, center=False scale=False, eps 1e-6, biased variance.   Replaces
  *     tf.contrib.layers.instance_norm at model_framework.py:423 and its gradient.
- * stats f32 [B][stats_tiles][C][2] = partial (sum, sum of squares) over H*W as produced by
+ * stats f32 [B][stats_tiles][C][2] = partial (sum, sum of squares) of (a - shift) over H*W as produced by
  * cutie_conv_fwd or cutie_in_stats; every consumer adds the slots of a (b, c) in slot order.
+ * The shift: shift[c] = act(shift_bias[c]) with act = the activation code (0 none, 1 ReLU, 2 sigmoid), 0 when
+ * shift_bias is NULL.  It makes mean = shift + S1/N, var = S2/N - (S1/N)^2 well conditioned in f32 for a
+ * channel whose bias dominates it (mean >> std); a channel of an instance-normalised layer's input that is
+ * nearly constant for another reason still cancels.  Producer and consumers of one `stats` array must be
+ * given the same (shift_bias, act); cutie_conv_fwd uses its own bias and activation.
  *   apply:     y = (a - mean) * rsqrt(var + eps)
  *   bwd_stats: red[b][t][c] = (sum dy, sum dy*xhat) over the t-th of red_tiles slices of H*W
  *   bwd_apply: dz = [a > 0] * inv * (dy - red0/HW - xhat*red1/HW);  dbias_part[b*dbias_tiles + t][c]
@@ -223,18 +232,20 @@ int cutie_pack_weights_batched(const cutie_pack_desc* descs, int n, int dtype, c
  */
 int cutie_in_tiles(int B, int HW, int C);
 int cutie_in_stats(const void* a, int ld_a, int a_dtype, int B, int HW, int C, float* stats,
-                   int stats_tiles, cutie_stream_t stream);
+                   int stats_tiles, const float* shift_bias, int shift_act, cutie_stream_t stream);
 int cutie_in_apply(const void* a, int ld_a, int a_dtype, const float* stats, int stats_tiles,
                    float eps, void* y, int ld_y, int y_dtype, int B, int HW, int C,
-                   cutie_stream_t stream);
+                   const float* shift_bias, int shift_act, cutie_stream_t stream);
 int cutie_in_bwd_stats(const void* dy, int ld_dy, int dy_dtype, const void* a, int ld_a,
                        int a_dtype, const float* stats, int stats_tiles, float eps, float* red,
-                       int red_tiles, int B, int HW, int C, cutie_stream_t stream);
+                       int red_tiles, int B, int HW, int C, const float* shift_bias, int shift_act,
+                       cutie_stream_t stream);
 int cutie_in_bwd_apply(const void* dy, int ld_dy, int dy_dtype, const void* a, int ld_a,
                        int a_dtype, const float* stats, int stats_tiles, float eps,
                        const float* red, int red_tiles, int relu,
                        void* dz, int ld_dz, int dz_dtype, float* dbias_part, int dbias_tiles,
-                       int B, int HW, int C, cutie_stream_t stream);
+                       int B, int HW, int C, const float* shift_bias /* act = relu */,
+                       cutie_stream_t stream);
 /* out[c] (+)= sum over b of part[b][c] */
 int cutie_sum_rows(const float* part, int B, int C, float* out, int accumulate, cutie_stream_t stream);
 /* the same for up to CUTIE_MAX_BATCH (part, out, C) triples in ONE launch: the bias gradients of

@@ -239,7 +239,8 @@ def test_conv_fwd(ops, dt, case):
     tol = 1e-4 if dt == "f32" else 2e-3      # f32 accumulate of bf16 products; inputs identical
     assert relerr(out[..., :cout], ref_a) < tol
     assert torch.all(out[..., cout:] == 3.0)
-    ref_s = torch.stack([ref_a.sum(dim=(1, 2)), (ref_a ** 2).sum(dim=(1, 2))], dim=-1)
+    sh = torch.relu(bias.double())                          # the moments are kept about act(bias) (cutie_hip.h, K6)
+    ref_s = torch.stack([(ref_a - sh).sum(dim=(1, 2)), ((ref_a - sh) ** 2).sum(dim=(1, 2))], dim=-1)
     assert relerr(stats.sum(dim=1), ref_s) < (1e-4 if dt == "f32" else 2e-3)
     assert float(stats[:, -1].abs().max()) == 0.0           # a slot no tile owns stays untouched
     # no float atomics: a second launch reproduces output and moments bit for bit
@@ -314,7 +315,8 @@ def test_conv_wide_16bit(ops, case, dt):
     # against the rounded reference the only differences are last-bit rounding flips
     assert (out[..., :cout].float().cpu() - ref_a.float().to(tdt).float()).abs().max() < (0.009 if dt == "f16" else 0.07)
     assert torch.all(out[..., cout:] == 3.0)
-    ref_s = torch.stack([ref_a.sum(dim=(1, 2)), (ref_a ** 2).sum(dim=(1, 2))], dim=-1)
+    sh = torch.relu(bias.double())                          # the moments are kept about act(bias)
+    ref_s = torch.stack([(ref_a - sh).sum(dim=(1, 2)), ((ref_a - sh) ** 2).sum(dim=(1, 2))], dim=-1)
     assert relerr(stats.sum(dim=1), ref_s) < 2e-3
     out2, stats2 = torch.full_like(out, 3.0), torch.zeros_like(stats)
     ops.conv_fwd([dict(x=xd[..., 32:32 + cin], w=wf, cin=cin, kh=kh, kw=kw, dil=dil)], out2[..., :cout], cout,
@@ -593,6 +595,65 @@ def test_instance_norm_fwd_bwd(ops, dt, C):
     tol = 1e-4 if dt == "f32" else 8e-3
     assert relerr(dz[..., :C], da_ref) < tol
     assert relerr(db, da_ref.sum(dim=(0, 1, 2))) < tol
+
+
+def test_instance_norm_channel_dominated_by_its_bias(ops):
+    """A channel with mean >> std (bias 50, sigma 0.01: the amplification case of SURVEY.md 7 - the norm multiplies it
+    by ~100): f32 E[x^2] - E[x]^2 loses the whole variance (2500.0001 - 2500), so the moments are kept about
+    act(bias).  Forward and backward of the norm against float64, through the conv epilogue's moments and through
+    cutie_in_stats, f32 path."""
+    g = torch.Generator().manual_seed(8)
+    B, H, W, Cin, C = 2, 40, 64, 64, 128
+    x = torch.randn((B, H, W, Cin), generator=g)
+    w = torch.randn((3, 5, Cin, C), generator=g) * 0.05
+    bias = torch.zeros(C)
+    w[..., 5] *= 0.01 / 0.05 / (15 * Cin) ** 0.5       # channel 5: conv output sigma ~0.01 ...
+    bias[5] = 50.0                                      # ... on top of a bias of 50
+    w[..., 9] *= 0.02
+    bias[9] = -30.0                                     # channel 9: dead behind the ReLU (all zeros, shift 0)
+    wf, _ = ops.pack_weights(w.to(DEV), CDT["f32"], want_dgrad=False)
+    T = ops.conv_stats_tiles(H, W)
+    a = torch.zeros((B, H, W, C), dtype=torch.float32, device=DEV)
+    stats = torch.zeros((B, T, C, 2), dtype=torch.float32, device=DEV)
+    bd = bias.to(DEV)
+    ops.conv_fwd([dict(x=x.to(DEV), w=wf, cin=wf.shape[2], kh=3, kw=5, dil=1)], a, C, bias=bd, relu=True, stats=stats)
+    y = torch.zeros_like(a)
+    ops.in_apply(a, stats, y, bias=bd, relu=True)
+    z64 = co.conv_raw(x.double(), w.double(), 1) + bias.double()
+    a64 = torch.relu(z64).requires_grad_(True)
+    y_ref = co.instance_norm(a64)
+    std5 = float(a64[..., 5].std())
+    assert 0.005 < std5 < 0.02 and float(a64[..., 5].mean()) > 49
+    assert relerr(a, a64) < 1e-6
+    e_all = relerr(y, y_ref)
+    e5 = float((y[..., 5].double().cpu() - y_ref[..., 5]).abs().max() / y_ref[..., 5].abs().max())
+    print("mean >> std channel: y error %.2e (all channels %.2e)" % (e5, e_all))
+    assert e5 < 2e-3 and e_all < 2e-3                   # a itself carries 50 * 2^-24 = 3e-6 of rounding on sigma 0.01
+    assert float(y[..., 9].abs().max()) == 0.0
+    # the same moments from cutie_in_stats, and the norm's gradient
+    stats2 = torch.zeros((B, 4, C, 2), dtype=torch.float32, device=DEV)
+    ops.in_stats(a, stats2, bias=bd, relu=True)
+    y2 = torch.zeros_like(a)
+    ops.in_apply(a, stats2, y2, bias=bd, relu=True)
+    assert relerr(y2, y) < 1e-3
+    dy = torch.randn((B, H, W, C), generator=g)
+    (y_ref * dy.double()).sum().backward()
+    da_ref = a64.grad * (a64.detach() > 0)
+    red = torch.zeros((B, 3, C, 2), dtype=torch.float32, device=DEV)
+    ops.in_bwd_stats(dy.to(DEV), a, stats, red, bias=bd, relu=True)
+    dz = torch.zeros_like(a)
+    ops.in_bwd_apply(dy.to(DEV), a, stats, red, dz, relu=True, bias=bd)
+    e5 = float((dz[..., 5].double().cpu() - da_ref[..., 5]).abs().max() / da_ref[..., 5].abs().max())
+    print("mean >> std channel: dz error %.2e" % e5)
+    assert e5 < 5e-3 and relerr(dz, da_ref) < 5e-3
+    # without the shift the channel's variance is gone: this is what the shift is for
+    stats0 = torch.zeros((B, 4, C, 2), dtype=torch.float32, device=DEV)
+    ops.in_stats(a, stats0)
+    y0 = torch.zeros_like(a)
+    ops.in_apply(a, stats0, y0)
+    e0 = float((y0[..., 5].double().cpu() - y_ref[..., 5]).abs().max() / y_ref[..., 5].abs().max())
+    print("mean >> std channel without the shift: y error %.2e" % e0)
+    assert e0 > 10 * e5
 
 
 @pytest.mark.parametrize("with_scratch", [False, True])
