@@ -46,7 +46,7 @@ struct ConvParams {
     // publishing its slot of bw_red every tile waits until the sample's other tiles have published theirs, folds all
     // slots and stores dz = act'(a) * inv * (dy - mean(dy) - xhat * mean(dy * xhat)) - what cutie_in_bwd_apply computes -
     // instead of dy, plus its share of the bias gradient.  `out` is not written then.
-    unsigned* rv_cnt;        // [B][n_tiles_n] arrival counters, only ever incremented (zeroed once by the caller)
+    unsigned long long* rv_slots;   // [B][bw_red_tiles][2][n_out] {value, tag} granules (zeroed once by the caller)
     char* rv_dz;
     int rv_ld_dz;
     float* rv_dbias;         // [B][rv_dbias_tiles][n_out], tile t of a sample stores row t

@@ -775,7 +775,7 @@ struct NormBwd {      // the reduction of cutie_in_bwd_stats, asked of a data-gr
     int ld_dz, relu;
     float* dbias;
     int dbias_tiles;
-    unsigned* sync;      // word 0: tiles whose wait ran out; then [B][n tiles] arrival counters
+    unsigned* sync;      // word 0: tiles whose wait ran out; from byte 64: [B][red_tiles][2][n_out] 8-byte granules
 };
 }  // namespace
 
@@ -798,7 +798,7 @@ static int conv_fwd_impl(const cutie_conv_seg* segs, int n_segs, int B, int H, i
     ConvParams p;
     p.nseg = n_segs;
     p.bw_a = nullptr; p.bw_ld_a = 0; p.bw_stats = nullptr; p.bw_stats_tiles = 0; p.bw_eps = 0.f; p.bw_bias = nullptr; p.bw_act = 0; p.bw_red = nullptr; p.bw_red_tiles = 0; p.perm_n = 0;
-    p.rv_cnt = nullptr; p.rv_dz = nullptr; p.rv_ld_dz = 0; p.rv_dbias = nullptr; p.rv_dbias_tiles = 0; p.rv_relu = 0; p.rv_plain_order = 0; p.rv_err = nullptr; p.rv_nowait = 0;
+    p.rv_slots = nullptr; p.rv_dz = nullptr; p.rv_ld_dz = 0; p.rv_dbias = nullptr; p.rv_dbias_tiles = 0; p.rv_relu = 0; p.rv_plain_order = 0; p.rv_err = nullptr; p.rv_nowait = 0;
     int twb, th_g;
     generic_tiling(W, th_g, twb);
     p.TWB = twb;
@@ -867,7 +867,8 @@ static int conv_fwd_impl(const cutie_conv_seg* segs, int n_segs, int B, int H, i
                        cutie::aligned16(nb->dz) && (!nb->dbias || q.tiles_h * q.tiles_w <= nb->dbias_tiles) &&
                        cutie::conv_wide_rendezvous_ok(q, bn, &plain);
                 if (meet) {
-                    q.rv_err = reinterpret_cast<int*>(nb->sync); q.rv_cnt = nb->sync + 1;      // word 0: timeouts
+                    q.rv_err = reinterpret_cast<int*>(nb->sync);      // word 0: timeouts; the granules start 64 bytes in
+                    q.rv_slots = reinterpret_cast<unsigned long long*>(nb->sync + 16);
                     q.rv_dz = (char*)nb->dz; q.rv_ld_dz = nb->ld_dz; q.rv_dbias = nb->dbias; q.rv_dbias_tiles = nb->dbias_tiles;
                     q.rv_relu = nb->relu; q.rv_plain_order = plain; q.rv_nowait = cutie::config().rv_nowait ? 1 : 0;
                 }
@@ -922,9 +923,9 @@ extern "C" int cutie_conv_dgrad_in_stats(const cutie_conv_seg* segs, int n_segs,
     return conv_fwd_impl(segs, n_segs, B, H, W, n_out, out, ld_out, out_dtype, nullptr, 0, nullptr, 0, dtype, &nb, stream_);
 }
 
-extern "C" size_t cutie_conv_sync_bytes(int B, int n_out) {
-    if (B < 0 || n_out < 1) return 0;
-    return ((size_t)B * (size_t)cutie::cdiv(n_out, 64) + 1) * sizeof(unsigned);
+extern "C" size_t cutie_conv_sync_bytes(int B, int red_tiles, int n_out) {
+    if (B < 0 || red_tiles < 1 || n_out < 1) return 0;
+    return 64 + (size_t)B * red_tiles * 2 * n_out * sizeof(unsigned long long);
 }
 
 extern "C" int cutie_conv_dgrad_in_bwd(const cutie_conv_seg* segs, int n_segs, int B, int H, int W, int n_out, void* dy,
@@ -943,8 +944,9 @@ extern "C" int cutie_conv_dgrad_in_bwd(const cutie_conv_seg* segs, int n_segs, i
     CUTIE_CHECK_ARG(!dbias_part || (dbias_tiles >= 1 && dbias_tiles <= 65535), "conv_dgrad_in_bwd: dbias_tiles=%d", dbias_tiles);
     CUTIE_CHECK_ARG((reinterpret_cast<uintptr_t>(stats) & 7) == 0 && (reinterpret_cast<uintptr_t>(red) & 7) == 0,
                     "conv_dgrad_in_bwd: stats and red must be 8-byte aligned");
-    if (sync && (sync_bytes < cutie_conv_sync_bytes(B, n_out) || (reinterpret_cast<uintptr_t>(sync) & 3))) {
-        cutie::set_error("conv_dgrad_in_bwd: sync area %zu < %zu bytes", sync_bytes, cutie_conv_sync_bytes(B, n_out));
+    if (sync && (sync_bytes < cutie_conv_sync_bytes(B, red_tiles, n_out) || (reinterpret_cast<uintptr_t>(sync) & 63))) {
+        cutie::set_error("conv_dgrad_in_bwd: sync area %zu < %zu bytes (or not 64-byte aligned)", sync_bytes,
+                         cutie_conv_sync_bytes(B, red_tiles, n_out));
         return CUTIE_E_WORKSPACE;
     }
     const NormBwd nb = {a, ld_a, dtype, stats, stats_tiles, eps, red, red_tiles, shift_bias, relu, dz, ld_dz, relu, dbias_part,

@@ -74,7 +74,11 @@ __device__ __forceinline__ void conv_wide_epilogue(const ConvParams& p, float4_t
     constexpr int IT = 256 / RG;         // store iterations per lane: 16 / 8 / 4
     const int pc = tid % PPR, rg = tid / PPR;
     const bool bw = p.bw_a != nullptr;
-    const bool rv = bw && p.rv_cnt != nullptr;
+    const bool rv = bw && p.rv_slots != nullptr;
+    unsigned rv_tag = 0;
+    if (rv)      // this launch's tag = the tag this tile's slot holds from the previous launch + 1 (all slots move in step)
+        rv_tag = (unsigned)(__hip_atomic_load(p.rv_slots + (((long long)b * p.bw_red_tiles + tile) * 2) * n_out + n0,
+                                              __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> 32) + 1u;
 
     // the forward activation pieces and the forward moments are requested first: their latency passes
     // under the staging of the accumulators
@@ -206,63 +210,61 @@ __device__ __forceinline__ void conv_wide_epilogue(const ConvParams& p, float4_t
             s1 += v.x;
             s2 += v.y;
         }
-        float* slot = p.bw_red + (((long long)b * p.bw_red_tiles + tile) * n_out + n0 + tid) * 2;
         if (rv) {
-            // other workgroups read this slot inside this launch: write-through 8-byte store (global_store_dwordx2 sc1;
-            // a wave's 64 lanes cover whole 128-byte lines), MI355X_MICROARCH.md "Valid forms", third row of the table
-            const unsigned long long bits = ((unsigned long long)__float_as_uint(s2) << 32) | __float_as_uint(s1);
-            __hip_atomic_store(reinterpret_cast<unsigned long long*>(slot), bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // other workgroups read these sums inside this launch.  Each goes out as ONE naturally aligned 8-byte
+            // {value, tag} granule by a write-through store (global_store_dwordx2 sc1): whoever reads a granule with
+            // the launch's tag has its value, with no ordering between the two sums or against a flag
+            // (MI355X_MICROARCH.md, granule hand-off).  The tag of a launch is the slot's previous tag + 1: every
+            // launch on a sync area rewrites all of its slots, so all tags move in step.
+            unsigned long long* g1 = p.rv_slots + (((long long)b * p.bw_red_tiles + tile) * 2 + 0) * n_out + n0 + tid;
+            unsigned long long* g2 = p.rv_slots + (((long long)b * p.bw_red_tiles + tile) * 2 + 1) * n_out + n0 + tid;
+            __hip_atomic_store(g1, ((unsigned long long)rv_tag << 32) | __float_as_uint(s1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(g2, ((unsigned long long)rv_tag << 32) | __float_as_uint(s2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         } else {
-            *reinterpret_cast<float2*>(slot) = make_float2(s1, s2);
+            *reinterpret_cast<float2*>(p.bw_red + (((long long)b * p.bw_red_tiles + tile) * n_out + n0 + tid) * 2) = make_float2(s1, s2);
         }
     }
     if (!rv) return;
 
-    // ---- rendezvous: every storing wave drains its stores, the workgroup meets, ONE lane announces the tile and
-    // polls the sample's counter (bounded), the workgroup meets again, then everybody reads the sample's slots by
-    // sc1 loads.  The counter only grows: a launch adds exactly T to it per sample, so the target is the next
-    // multiple of T above the value the add returned.
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    // ---- rendezvous: every channel lane sweeps the granules of the sample's tiles until all carry this launch's tag
+    // (bounded), then folds them in slot order - the arithmetic of norm.hip's fold.  No flag, no counter, no fence.
     const int T = p.tiles_h * p.tiles_w;
-    if (tid == 0) {
-        unsigned* cnt = p.rv_cnt + (long long)b * p.n_tiles_n + (n0 / BN);
-        const unsigned old = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const unsigned target = old - old % (unsigned)T + (unsigned)T;
-        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();      // 100 MHz
-        bool ok = true;
-        while (!p.rv_nowait && (int)(__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {
-            __builtin_amdgcn_s_sleep(8);
-            if (__builtin_amdgcn_s_memrealtime() - t0 > 20000000ull) {      // 0.2 s: the other tiles never came
-                ok = false;
-                break;
-            }
-        }
-        if (!ok) atomicAdd(p.rv_err, 1);
-    }
-    __syncthreads();
     float* tab2 = reinterpret_cast<float*>(smem + S::WSUM);      // [2][BN]: mean(dy), mean(dy * xhat)
     if (tid < BN && n0 + tid < n_out) {
-        float r1 = 0.f, r2 = 0.f;
         const float inv_n = 1.f / (float)(H * W);
-        // slot order, as norm.hip's fold; sixteen slots' loads are in flight together (one memory round trip, not four)
-        for (int t0 = 0; t0 < p.bw_red_tiles; t0 += 16) {
-            unsigned v1[16], v2[16];
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();      // 100 MHz
+        float r1 = 0.f, r2 = 0.f;
+        bool late = false;
+        while (true) {
+            bool all = true;
+            r1 = 0.f;
+            r2 = 0.f;
+            for (int tb = 0; tb < T; tb += 16) {       // sixteen tiles' granules in flight together
+                unsigned long long v1[16], v2[16];
 #pragma unroll
-            for (int u = 0; u < 16; ++u) {
-                const int t = t0 + u < p.bw_red_tiles ? t0 + u : p.bw_red_tiles - 1;
-                const unsigned* q = reinterpret_cast<const unsigned*>(p.bw_red + (((long long)b * p.bw_red_tiles + t) * n_out + n0 + tid) * 2);
-                v1[u] = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                v2[u] = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
+                for (int u = 0; u < 16; ++u) {
+                    const int t = tb + u < T ? tb + u : T - 1;
+                    const unsigned long long* q = p.rv_slots + ((long long)b * p.bw_red_tiles + t) * 2 * n_out + n0 + tid;
+                    v1[u] = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    v2[u] = __hip_atomic_load(q + n_out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
 #pragma unroll
-            for (int u = 0; u < 16; ++u) {
-                if (t0 + u < p.bw_red_tiles) {
-                    r1 += __uint_as_float(v1[u]);
-                    r2 += __uint_as_float(v2[u]);
+                for (int u = 0; u < 16; ++u) {
+                    if (tb + u < T) {
+                        all = all && (unsigned)(v1[u] >> 32) == rv_tag && (unsigned)(v2[u] >> 32) == rv_tag;
+                        r1 += __uint_as_float((unsigned)v1[u]);
+                        r2 += __uint_as_float((unsigned)v2[u]);
+                    }
                 }
             }
+            if (all || p.rv_nowait) break;
+            if (__builtin_amdgcn_s_memrealtime() - t0 > 20000000ull) {      // 0.2 s: the other tiles never came
+                late = true;
+                break;
+            }
+            __builtin_amdgcn_s_sleep(4);
         }
+        if (late && (tid & 63) == 0) atomicAdd(p.rv_err, 1);
         tab2[tid] = r1 * inv_n;
         tab2[BN + tid] = r2 * inv_n;
     }
@@ -664,7 +666,7 @@ static void plan_tile_order(ConvParams& p) {
     const bool on = config().conv_lpt;
     p.perm_n = 0;
     const int nt = p.tiles_h * p.tiles_w;
-    if (p.rv_cnt) return;      // a rendezvous wants a sample's tiles side by side in dispatch order
+    if (p.rv_slots) return;      // a rendezvous wants a sample's tiles side by side in dispatch order
     if (!on || nt < 2 || nt > CONV_MAX_PERM || (p.B & 7) != 0) return;
     int weight[CONV_MAX_PERM];
     int wmin, wmax;

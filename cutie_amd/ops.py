@@ -161,15 +161,15 @@ def _seg_array(segs, out, n_out, what):
     return arr, dt
 
 
-def conv_sync_bytes(B, n_out):
-    return capi.lib().cutie_conv_sync_bytes(int(B), int(n_out))
+def conv_sync_bytes(B, red_tiles, n_out):
+    return capi.lib().cutie_conv_sync_bytes(int(B), int(red_tiles), int(n_out))
 
 
 def conv_dgrad_in_bwd(segs, dy, n_out, a, stats, red, dz, dbias_part=None, relu=True, sync=None, eps=IN_EPS, bias=None):
     """Data gradient of an instance-normalised layer and the gradient of its norm + activation in one call
     (cutie_conv_dgrad_in_bwd): segs as conv_fwd (flip=True), dy = scratch view [B,H,W,>=n_out], a / stats = the layer's
     forward activation and moments, red = f32 [B,T,n_out,2] zeroed once, dz = output view, dbias_part f32 [B*T', n_out],
-    sync = int32 tensor of conv_sync_bytes(B, n_out) bytes zeroed once and dedicated to this layer and shape
+    sync = int32 tensor of conv_sync_bytes(B, T, n_out) bytes zeroed once and dedicated to this layer and shape
     (None: two-call form).  sync[0] counts tiles whose bounded wait ran out.  bias: the layer's bias - with `relu` the
     shift its moments are kept about (None when they were produced without one)."""
     B = dy.shape[0]

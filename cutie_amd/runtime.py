@@ -245,8 +245,8 @@ class Engine(object):
             # the one-launch data gradient (conv_dgrad_in_bwd) leaves one bias-gradient row per conv tile
             fusable = n.name != net.loss_logits_name and self.dt != F32
             P.dbpart[n.name] = torch.zeros((B * (max(ct, t) if fusable else t), n.channels), dtype=torch.float32, device=dev)
-            # arrival counters of that launch's tile rendezvous (word 0: timeouts); zeroed once, then the library's
-            P.sync[n.name] = torch.zeros(ops.conv_sync_bytes(B, n.channels) // 4, dtype=torch.int32, device=dev)
+            # tagged granules of that launch's tile rendezvous (word 0: timeouts); zeroed once, then the library's
+            P.sync[n.name] = torch.zeros(ops.conv_sync_bytes(B, ct, n.channels) // 4, dtype=torch.int32, device=dev)
         # gradient buffers for every tensor that a conv, the embedding or the sampler produces
         P.ps_acc = {}
         for n in net.nodes:

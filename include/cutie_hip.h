@@ -159,18 +159,19 @@ int cutie_conv_dgrad_in_stats(const cutie_conv_seg* segs /* host */, int n_segs,
  * cutie_conv_dgrad_in_stats followed by cutie_in_bwd_apply (K6 below), asked for as one call:
  *   dz = act'(a) * inv * (dy - mean(dy) - xhat * mean(dy * xhat)),  dbias_part[b*dbias_tiles + t][c] = partial sums of dz.
  * Where the wide MFMA kernel applies, the tiles of a sample take about equally long and at most 128 workgroups
- * make up a sample, ONE launch does it: every tile publishes its slot of `red`, the sample's tiles meet on a
- * counter in `sync` (a bounded wait), fold the slots and store dz straight from the tile - dy is never written and
- * the pass over dy, a and dz does not run (the same bits as the two-call form: same operands, same order).
- * Otherwise the call runs the two-call form through `dy`.  Either way `dy` must be a valid [B,H,W,>=n_out] scratch.
- *   sync: cutie_conv_sync_bytes(B, n_out) bytes, 4-byte aligned, zeroed ONCE by the caller and then left to the
- *         library, one area per (layer, shape): its counters only grow, by the tile count per launch.  Word 0 counts
- *         tiles whose wait ran out (0.2 s: a sample's workgroups were not resident together) - the results of such a
+ * make up a sample, ONE launch does it: every tile publishes its two sums as tagged 8-byte granules in `sync`,
+ * sweeps the granules of its sample's other tiles until they carry the launch's tag (a bounded wait), folds them
+ * and stores dz straight from the tile - dy is never written and the pass over dy, a and dz does not run (the
+ * same bits as the two-call form: same operands, same order).  Otherwise the call runs the two-call form through
+ * `dy` and `red`.  Either way `dy` must be a valid [B,H,W,>=n_out] scratch and `red` a valid slot array.
+ *   sync: cutie_conv_sync_bytes(B, red_tiles, n_out) bytes, 64-byte aligned, zeroed ONCE by the caller and then left
+ *         to the library, one area per (layer, shape): a launch's tag is the previous launch's + 1.  Word 0 counts
+ *         waits that ran out (0.2 s: a sample's workgroups were not resident together) - the results of such a
  *         launch are invalid; read it at a synchronisation point.  NULL selects the two-call form.
  *   dbias_part (nullable): dbias_tiles >= cutie_conv_stats_tiles(H, W); tile t of a sample STORES row t, rows the
  *         launch does not own are left alone (zero the array once when it is allocated), as for `red`.
  * CUTIE_RENDEZVOUS=0 in the environment when the library is loaded selects the two-call form everywhere. */
-size_t cutie_conv_sync_bytes(int B, int n_out);
+size_t cutie_conv_sync_bytes(int B, int red_tiles, int n_out);
 int cutie_conv_dgrad_in_bwd(const cutie_conv_seg* segs /* host */, int n_segs,
                             int B, int H, int W, int n_out,
                             void* dy, int ld_dy,

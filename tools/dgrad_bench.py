@@ -26,7 +26,7 @@ red = torch.zeros((B, T, C, 2), device=dev)
 dbp = torch.zeros((B * 32, C), device=dev)
 dy = torch.zeros((B, H, W, C), dtype=tdt, device=dev)
 dz = torch.zeros((B, H, W, C), dtype=tdt, device=dev)
-sync = torch.zeros(ops.conv_sync_bytes(B, C) // 4, dtype=torch.int32, device=dev)
+sync = torch.zeros(ops.conv_sync_bytes(B, T, C) // 4, dtype=torch.int32, device=dev)
 seg = [dict(x=dzin, w=wd, cin=C, kh=3, kw=5, dil=dil, flip=True)]
 
 
