@@ -21,7 +21,7 @@ w = (torch.randn((kh, kw, cin, cout), generator=g) * 0.05).to(dev)
 wf, wd = ops.pack_weights(w, capi.BF16)
 out = torch.zeros((B, H, W, cout), dtype=torch.bfloat16, device=dev)
 bias = torch.zeros(cout, device=dev)
-stats = torch.zeros((B, cout, 2), device=dev)
+stats = torch.zeros((B, ops.conv_stats_tiles(H, W), cout, 2), device=dev)
 dw = torch.zeros((kh, kw, cin, cout), device=dev)
 ws = torch.empty(ops.conv_wgrad_workspace_bytes(B, H, W, cin, cout, kh, kw), dtype=torch.uint8, device=dev)
 
