@@ -55,6 +55,11 @@ struct ConvParams {
     int rv_plain_order;      // 1: block ids in launch order (a sample's tiles spread over the XCDs)
     int rv_nowait;           // diagnostic (CUTIE_RV_NOWAIT=1): do not wait - WRONG results, prices the protocol without the waiting
     int* rv_err;             // [1]: tiles whose bounded wait ran out (the step's results are then invalid)
+    // Forward rendezvous (conv_wide only, with stats, nullable): the sample's tiles meet after publishing their moments
+    // and `out` receives the NORMALISED activation y = (a - mean) * rsqrt(var + fw_eps); a itself is not stored.
+    // Shares rv_plain_order / rv_nowait / rv_err with the backward form.
+    unsigned long long* fw_slots;   // [B][stats_tiles][2][n_out] {value, tag} granules (zeroed once by the caller)
+    float fw_eps;
     // conv_wide: order in which an XCD takes the pixel tiles of its samples - heaviest (most live taps)
     // first, so that the light corner tiles of a dilated layer fill the end of the launch.  0 = row-major.
     int perm_n;
@@ -135,5 +140,6 @@ __device__ __forceinline__ void glds16(u32x4s_t rsrc, unsigned lds_dst, unsigned
 int launch_conv_wide(const convk::ConvParams& p, int dtype, int bn, hipStream_t stream);
 int conv_wide_tile(const convk::ConvParams& p);
 bool conv_wide_rendezvous_ok(const convk::ConvParams& p, int bn, int* plain_order);
+bool conv_wide_fw_rendezvous_ok(const convk::ConvParams& p, int bn, int* plain_order);
 
 }  // namespace cutie

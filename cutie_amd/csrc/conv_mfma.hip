@@ -779,9 +779,18 @@ struct NormBwd {      // the reduction of cutie_in_bwd_stats, asked of a data-gr
 };
 }  // namespace
 
+namespace {
+struct NormFwd {      // cutie_conv_in_fwd: the normalised output, asked of a forward launch
+    void* y;
+    int ld_y;
+    float eps;
+    unsigned* sync;      // word 0: waits that ran out; from byte 64: [B][stats_tiles][2][n_out] 8-byte granules
+};
+}  // namespace
+
 static int conv_fwd_impl(const cutie_conv_seg* segs, int n_segs, int B, int H, int W, int n_out, void* out,
                          int ld_out, int out_dtype, const float* bias, int relu, float* stats, int stats_tiles,
-                         int dtype, const NormBwd* nb, cutie_stream_t stream_) {
+                         int dtype, const NormBwd* nb, cutie_stream_t stream_, const NormFwd* nf = nullptr) {
     hipStream_t stream = (hipStream_t)stream_;
     CUTIE_CHECK_ARG(segs && n_segs >= 1 && n_segs <= CUTIE_MAX_SEGS, "conv_fwd: n_segs=%d (1..%d)", n_segs, CUTIE_MAX_SEGS);
     CUTIE_CHECK_ARG(B >= 0 && H >= 1 && W >= 1 && n_out >= 1 && ld_out >= n_out, "conv_fwd: bad sizes B=%d H=%d W=%d n_out=%d ld_out=%d",
@@ -798,7 +807,7 @@ static int conv_fwd_impl(const cutie_conv_seg* segs, int n_segs, int B, int H, i
     ConvParams p;
     p.nseg = n_segs;
     p.bw_a = nullptr; p.bw_ld_a = 0; p.bw_stats = nullptr; p.bw_stats_tiles = 0; p.bw_eps = 0.f; p.bw_bias = nullptr; p.bw_act = 0; p.bw_red = nullptr; p.bw_red_tiles = 0; p.perm_n = 0;
-    p.rv_slots = nullptr; p.rv_dz = nullptr; p.rv_ld_dz = 0; p.rv_dbias = nullptr; p.rv_dbias_tiles = 0; p.rv_relu = 0; p.rv_plain_order = 0; p.rv_err = nullptr; p.rv_nowait = 0;
+    p.rv_slots = nullptr; p.rv_dz = nullptr; p.rv_ld_dz = 0; p.rv_dbias = nullptr; p.rv_dbias_tiles = 0; p.rv_relu = 0; p.rv_plain_order = 0; p.rv_err = nullptr; p.rv_nowait = 0; p.fw_slots = nullptr; p.fw_eps = 0.f;
     int twb, th_g;
     generic_tiling(W, th_g, twb);
     p.TWB = twb;
@@ -873,9 +882,19 @@ static int conv_fwd_impl(const cutie_conv_seg* segs, int n_segs, int B, int H, i
                     q.rv_relu = nb->relu; q.rv_plain_order = plain; q.rv_nowait = cutie::config().rv_nowait ? 1 : 0;
                 }
             }
+            if (nf && !nb && stats && cutie::config().rendezvous && relu != 2 && (nf->ld_y * 2) % 16 == 0 && cutie::aligned16(nf->y)) {
+                int plain = 0;
+                if (cutie::conv_wide_fw_rendezvous_ok(q, bn, &plain)) {      // the tiles meet: y goes out, a does not
+                    q.out = (char*)nf->y; q.ld_out = nf->ld_y;
+                    q.fw_slots = reinterpret_cast<unsigned long long*>(nf->sync + 16); q.fw_eps = nf->eps;
+                    q.rv_err = reinterpret_cast<int*>(nf->sync); q.rv_plain_order = plain;
+                    q.rv_nowait = cutie::config().rv_nowait ? 1 : 0;
+                    meet = true;
+                }
+            }
             const int rc = cutie::launch_conv_wide(q, dtype, bn, stream);
             if (rc != CUTIE_OK) return rc;
-            if (meet) return 1;      // positive: dz and dbias are in place (callers inside this file only)
+            if (meet) return 1;      // positive: the launch did the norm too (callers inside this file only)
             if (fuse || !nb) return rc;
             return cutie_in_bwd_stats(out, ld_out, out_dtype, nb->a, nb->ld_a, nb->a_dtype, nb->stats, nb->stats_tiles, nb->eps,
                                       nb->red, nb->red_tiles, B, H * W, n_out, nb->bias, nb->act, stream_);
@@ -904,6 +923,25 @@ extern "C" int cutie_conv_fwd(const cutie_conv_seg* segs, int n_segs, int B, int
                               int dtype, cutie_stream_t stream_) {
     return conv_fwd_impl(segs, n_segs, B, H, W, n_out, out, ld_out, out_dtype, bias, relu, stats, stats_tiles, dtype, nullptr,
                          stream_);
+}
+
+extern "C" int cutie_conv_in_fwd(const cutie_conv_seg* segs, int n_segs, int B, int H, int W, int n_out, void* a, int ld_a,
+                                 void* y, int ld_y, const float* bias, int relu, float* stats, int stats_tiles, float eps,
+                                 void* sync, size_t sync_bytes, int dtype, cutie_stream_t stream_) {
+    CUTIE_CHECK_ARG(B >= 0 && H >= 1 && W >= 1 && n_out >= 1, "conv_in_fwd: bad sizes");
+    if (B == 0) return CUTIE_OK;
+    CUTIE_CHECK_ARG(a && y && stats && ld_a >= n_out && ld_y >= n_out, "conv_in_fwd: null pointer or leading dimension < n_out");
+    if (sync && (sync_bytes < cutie_conv_sync_bytes(B, stats_tiles, n_out) || (reinterpret_cast<uintptr_t>(sync) & 63))) {
+        cutie::set_error("conv_in_fwd: sync area %zu < %zu bytes (or not 64-byte aligned)", sync_bytes,
+                         cutie_conv_sync_bytes(B, stats_tiles, n_out));
+        return CUTIE_E_WORKSPACE;
+    }
+    const NormFwd nf = {y, ld_y, eps, (unsigned*)sync};
+    const int rc = conv_fwd_impl(segs, n_segs, B, H, W, n_out, a, ld_a, dtype, bias, relu, stats, stats_tiles, dtype, nullptr,
+                                 stream_, sync ? &nf : nullptr);
+    if (rc == 1) return CUTIE_OK;      // one launch did all of it; `a` was not written
+    if (rc != CUTIE_OK) return rc;
+    return cutie_in_apply(a, ld_a, dtype, stats, stats_tiles, eps, y, ld_y, dtype, B, H * W, n_out, bias, relu, stream_);
 }
 
 extern "C" int cutie_conv_dgrad_in_stats(const cutie_conv_seg* segs, int n_segs, int B, int H, int W, int n_out, void* out,

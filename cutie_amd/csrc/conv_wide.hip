@@ -54,6 +54,57 @@ template <int DT> __device__ __forceinline__ void unpack8(const uint4& u, float*
     }
 }
 
+// Rendezvous of a sample's tiles on tagged 8-byte granules (MI355X_MICROARCH.md, granule hand-off).  slots:
+// [B][slot_tiles][2][n_out] {value, tag}; a tile publishes its two sums for channel c with the launch's tag, then
+// every channel lane sweeps the sample's T tiles until all granules carry that tag (bounded) and folds them in slot
+// order.  The tag of a launch is the slot's previous tag + 1: every launch rewrites all slots of its area.
+__device__ __forceinline__ unsigned granule_tag(const unsigned long long* slots, int b, int slot_tiles, int tile, int n_out, int c) {
+    return (unsigned)(__hip_atomic_load(slots + (((long long)b * slot_tiles + tile) * 2) * n_out + c, __ATOMIC_RELAXED,
+                                        __HIP_MEMORY_SCOPE_AGENT) >> 32) + 1u;
+}
+__device__ __forceinline__ void granule_publish(unsigned long long* slots, int b, int slot_tiles, int tile, int n_out, int c,
+                                                unsigned tag, float s1, float s2) {
+    // write-through 8-byte stores (global_store_dwordx2 sc1): whoever reads a granule with the tag has its value
+    unsigned long long* g1 = slots + (((long long)b * slot_tiles + tile) * 2) * n_out + c;
+    __hip_atomic_store(g1, ((unsigned long long)tag << 32) | __float_as_uint(s1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(g1 + n_out, ((unsigned long long)tag << 32) | __float_as_uint(s2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void granule_sweep(const unsigned long long* slots, int b, int slot_tiles, int T, int n_out, int c,
+                                              unsigned tag, int nowait, int* err, float& r1, float& r2) {
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();      // 100 MHz
+    bool late = false;
+    while (true) {
+        bool all = true;
+        r1 = 0.f;
+        r2 = 0.f;
+        for (int tb = 0; tb < T; tb += 16) {       // sixteen tiles' granules in flight together
+            unsigned long long v1[16], v2[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const int t = tb + u < T ? tb + u : T - 1;
+                const unsigned long long* q = slots + ((long long)b * slot_tiles + t) * 2 * n_out + c;
+                v1[u] = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                v2[u] = __hip_atomic_load(q + n_out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                if (tb + u < T) {
+                    all = all && (unsigned)(v1[u] >> 32) == tag && (unsigned)(v2[u] >> 32) == tag;
+                    r1 += __uint_as_float((unsigned)v1[u]);
+                    r2 += __uint_as_float((unsigned)v2[u]);
+                }
+            }
+        }
+        if (all || nowait) break;
+        if (__builtin_amdgcn_s_memrealtime() - t0 > 20000000ull) {      // 0.2 s: the other tiles never came
+            late = true;
+            break;
+        }
+        __builtin_amdgcn_s_sleep(4);
+    }
+    if (late && (threadIdx.x & 63) == 0) atomicAdd(err, 1);
+}
+
 // bias, ReLU, instance-norm moments, LDS-staged coalesced store of a 256-pixel x BN-channel tile.
 // With p.bw_a (data gradient of an instance-normalised layer) the store pass also takes this tile's share of
 // (sum dy, sum dy * xhat) from the ROUNDED dy it stores and the layer's forward activation, so that
@@ -76,9 +127,10 @@ __device__ __forceinline__ void conv_wide_epilogue(const ConvParams& p, float4_t
     const bool bw = p.bw_a != nullptr;
     const bool rv = bw && p.rv_slots != nullptr;
     unsigned rv_tag = 0;
-    if (rv)      // this launch's tag = the tag this tile's slot holds from the previous launch + 1 (all slots move in step)
-        rv_tag = (unsigned)(__hip_atomic_load(p.rv_slots + (((long long)b * p.bw_red_tiles + tile) * 2) * n_out + n0,
-                                              __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> 32) + 1u;
+    if (rv) rv_tag = granule_tag(p.rv_slots, b, p.bw_red_tiles, tile, n_out, n0);
+    const bool fw = !bw && p.fw_slots != nullptr && p.stats != nullptr;     // forward: the tiles meet, y is stored, a is not
+    unsigned fw_tag = 0;
+    if (fw) fw_tag = granule_tag(p.fw_slots, b, p.stats_tiles, tile, n_out, n0);
 
     // the forward activation pieces and the forward moments are requested first: their latency passes
     // under the staging of the accumulators
@@ -137,7 +189,8 @@ __device__ __forceinline__ void conv_wide_epilogue(const ConvParams& p, float4_t
                 const float d = inside ? v - sh : 0.f;
                 s1 += d;
                 s2 += d * d;
-                store_from_f32(Cs + (mb * 16 + lg * 4 + r) * BN + cl, v);
+                if (fw) acc[m][n][r] = v;        // stays in registers until the sample's moments are known
+                else store_from_f32(Cs + (mb * 16 + lg * 4 + r) * BN + cl, v);
             }
         }
         if (p.stats) {
@@ -158,6 +211,35 @@ __device__ __forceinline__ void conv_wide_epilogue(const ConvParams& p, float4_t
             s2 += v.y;
         }
         *reinterpret_cast<float2*>(p.stats + (((long long)b * p.stats_tiles + tile) * n_out + n0 + tid) * 2) = make_float2(s1, s2);
+        if (fw) {
+            // forward rendezvous: publish, wait for the sample's other tiles, fold all of them in slot order (the
+            // arithmetic of norm.hip's fold_slots<1>) - this lane then knows its channel's mean and 1/sigma
+            granule_publish(p.fw_slots, b, p.stats_tiles, tile, n_out, n0 + tid, fw_tag, s1, s2);
+            float r1, r2;
+            granule_sweep(p.fw_slots, b, p.stats_tiles, p.tiles_h * p.tiles_w, n_out, n0 + tid, fw_tag, p.rv_nowait, p.rv_err, r1, r2);
+            const float inv_n = 1.f / (float)(H * W);
+            const float md = r1 * inv_n;
+            const float var = fmaxf(r2 * inv_n - md * md, 0.f);
+            const float bvv = p.bias ? p.bias[n0 + tid] : 0.f;
+            tab[tid] = md + (p.relu ? fmaxf(bvv, 0.f) : bvv);
+            tab[BN + tid] = rsqrtf(var + p.fw_eps);
+        }
+    }
+    if (fw) {
+        __syncthreads();
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+            const int cl = wn * 64 + n * 16 + li;
+            const float mean = tab[cl], inv = tab[BN + cl];
+#pragma unroll
+            for (int m = 0; m < S::MB; ++m) {
+                const int mb = wm * S::MB + m;
+#pragma unroll
+                for (int r = 0; r < 4; ++r)      // y = (a - mean) * inv from the UNROUNDED activation: one rounding
+                    store_from_f32(Cs + (mb * 16 + lg * 4 + r) * BN + cl, (acc[m][n][r] - mean) * inv);
+            }
+        }
+        __syncthreads();
     }
     const int col = n0 + pc * 8;
     float mean8[8], inv8[8], g1[8], g2[8];
@@ -211,15 +293,7 @@ __device__ __forceinline__ void conv_wide_epilogue(const ConvParams& p, float4_t
             s2 += v.y;
         }
         if (rv) {
-            // other workgroups read these sums inside this launch.  Each goes out as ONE naturally aligned 8-byte
-            // {value, tag} granule by a write-through store (global_store_dwordx2 sc1): whoever reads a granule with
-            // the launch's tag has its value, with no ordering between the two sums or against a flag
-            // (MI355X_MICROARCH.md, granule hand-off).  The tag of a launch is the slot's previous tag + 1: every
-            // launch on a sync area rewrites all of its slots, so all tags move in step.
-            unsigned long long* g1 = p.rv_slots + (((long long)b * p.bw_red_tiles + tile) * 2 + 0) * n_out + n0 + tid;
-            unsigned long long* g2 = p.rv_slots + (((long long)b * p.bw_red_tiles + tile) * 2 + 1) * n_out + n0 + tid;
-            __hip_atomic_store(g1, ((unsigned long long)rv_tag << 32) | __float_as_uint(s1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(g2, ((unsigned long long)rv_tag << 32) | __float_as_uint(s2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            granule_publish(p.rv_slots, b, p.bw_red_tiles, tile, n_out, n0 + tid, rv_tag, s1, s2);
         } else {
             *reinterpret_cast<float2*>(p.bw_red + (((long long)b * p.bw_red_tiles + tile) * n_out + n0 + tid) * 2) = make_float2(s1, s2);
         }
@@ -232,39 +306,8 @@ __device__ __forceinline__ void conv_wide_epilogue(const ConvParams& p, float4_t
     float* tab2 = reinterpret_cast<float*>(smem + S::WSUM);      // [2][BN]: mean(dy), mean(dy * xhat)
     if (tid < BN && n0 + tid < n_out) {
         const float inv_n = 1.f / (float)(H * W);
-        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();      // 100 MHz
-        float r1 = 0.f, r2 = 0.f;
-        bool late = false;
-        while (true) {
-            bool all = true;
-            r1 = 0.f;
-            r2 = 0.f;
-            for (int tb = 0; tb < T; tb += 16) {       // sixteen tiles' granules in flight together
-                unsigned long long v1[16], v2[16];
-#pragma unroll
-                for (int u = 0; u < 16; ++u) {
-                    const int t = tb + u < T ? tb + u : T - 1;
-                    const unsigned long long* q = p.rv_slots + ((long long)b * p.bw_red_tiles + t) * 2 * n_out + n0 + tid;
-                    v1[u] = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    v2[u] = __hip_atomic_load(q + n_out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-#pragma unroll
-                for (int u = 0; u < 16; ++u) {
-                    if (tb + u < T) {
-                        all = all && (unsigned)(v1[u] >> 32) == rv_tag && (unsigned)(v2[u] >> 32) == rv_tag;
-                        r1 += __uint_as_float((unsigned)v1[u]);
-                        r2 += __uint_as_float((unsigned)v2[u]);
-                    }
-                }
-            }
-            if (all || p.rv_nowait) break;
-            if (__builtin_amdgcn_s_memrealtime() - t0 > 20000000ull) {      // 0.2 s: the other tiles never came
-                late = true;
-                break;
-            }
-            __builtin_amdgcn_s_sleep(4);
-        }
-        if (late && (tid & 63) == 0) atomicAdd(p.rv_err, 1);
+        float r1, r2;
+        granule_sweep(p.rv_slots, b, p.bw_red_tiles, T, n_out, n0 + tid, rv_tag, p.rv_nowait, p.rv_err, r1, r2);
         tab2[tid] = r1 * inv_n;
         tab2[BN + tid] = r2 * inv_n;
     }
@@ -659,6 +702,25 @@ bool conv_wide_rendezvous_ok(const ConvParams& p, int bn, int* plain_order) {
     return true;
 }
 
+// The forward form (y stored instead of a, cutie_conv_in_fwd): the same residency rule; taken only where the tiles
+// are balanced to 6 % - a rule that does NOT depend on the batch size, because the fused and the two-call form round y
+// differently (from the f32 activation / from the stored 16-bit one) and a sample's output must not depend on how
+// many other samples share its batch.
+bool conv_wide_fw_rendezvous_ok(const ConvParams& p, int bn, int* plain_order) {
+    int weight[CONV_MAX_PERM];
+    int wmin, wmax;
+    if (!tile_weights(p, weight, wmin, wmax)) return false;
+    const int nt = p.tiles_h * p.tiles_w;
+    const int per_sample = nt * p.n_tiles_n;
+    if (per_sample > 128) return false;
+    double wavg = 0.0;
+    for (int t = 0; t < nt; ++t) wavg += weight[t];
+    wavg /= nt;
+    if (wmax - wavg > 0.06 * wavg) return false;
+    *plain_order = per_sample > 32 ? 1 : 0;
+    return true;
+}
+
 // Heaviest-first tile order (ConvParams::perm): the K steps of a tile are its live taps x channel chunks, which on
 // a dilated layer differ up to 2x between the centre and the corners of the image.  Dispatch is in block order, so
 // putting the heavy tiles first lets the light ones even out the end of the launch.
@@ -666,7 +728,7 @@ static void plan_tile_order(ConvParams& p) {
     const bool on = config().conv_lpt;
     p.perm_n = 0;
     const int nt = p.tiles_h * p.tiles_w;
-    if (p.rv_slots) return;      // a rendezvous wants a sample's tiles side by side in dispatch order
+    if (p.rv_slots || p.fw_slots) return;      // a rendezvous wants a sample's tiles side by side in dispatch order
     if (!on || nt < 2 || nt > CONV_MAX_PERM || (p.B & 7) != 0) return;
     int weight[CONV_MAX_PERM];
     int wmin, wmax;

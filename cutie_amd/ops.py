@@ -165,6 +165,20 @@ def conv_sync_bytes(B, red_tiles, n_out):
     return capi.lib().cutie_conv_sync_bytes(int(B), int(red_tiles), int(n_out))
 
 
+def conv_in_fwd(segs, a, y, n_out, bias, relu, stats, sync=None, eps=IN_EPS):
+    """conv + bias + activation + instance norm as one call (cutie_conv_in_fwd): a = scratch view for the pre-norm
+    activation, y = output view, stats as conv_fwd.  With `sync` (int32 tensor of conv_sync_bytes(B, T, n_out) bytes, zeroed
+    once, dedicated to this layer and shape) the launch may store y directly and leave `a` unwritten (inference)."""
+    B = y.shape[0]
+    arr, dt = _seg_array(segs, y, n_out, "conv_in_fwd")
+    if dt_of(a) != dt or dt_of(y) != dt:
+        raise capi.CutieError("conv_in_fwd: a and y must have the segments' dtype")
+    call("cutie_conv_in_fwd", arr, len(segs), B, y.shape[1], y.shape[2], n_out, ptr(a), ld_of(a), ptr(y), ld_of(y), ptr(bias),
+         ACTIVATION_CODE[relu], ptr(stats), _tiles(stats, B, n_out, True), eps, ptr(sync),
+         sync.numel() * sync.element_size() if sync is not None else 0, dt, stream())
+    return y
+
+
 def conv_dgrad_in_bwd(segs, dy, n_out, a, stats, red, dz, dbias_part=None, relu=True, sync=None, eps=IN_EPS, bias=None):
     """Data gradient of an instance-normalised layer and the gradient of its norm + activation in one call
     (cutie_conv_dgrad_in_bwd): segs as conv_fwd (flip=True), dy = scratch view [B,H,W,>=n_out], a / stats = the layer's

@@ -203,7 +203,7 @@ class Engine(object):
         tiles = {n.name: ops.conv_stats_tiles(*spatial(n)) for n in convs}
         n_stats = sum(B * tiles[n.name] * n.channels * 2 for n in convs)
         P.stats_all = torch.zeros(n_stats, dtype=torch.float32, device=dev)
-        P.a, P.stats, P.red, P.dz, P.dy, P.dbpart, P.sync = {}, {}, {}, {}, {}, {}, {}
+        P.a, P.stats, P.red, P.dz, P.dy, P.dbpart, P.sync, P.sync_fw = {}, {}, {}, {}, {}, {}, {}, {}
         so = 0
         for n in convs:
             hs, ws = spatial(n)
@@ -338,7 +338,10 @@ class Engine(object):
     # ------------------------------------------------------------------ execution
     def forward(self, grid, image=None, ps_1d_indices=None, labels=None):
         """grid int [B,H,W,1] or [B,H,W] (host or device).  Returns the plan holding every
-        named layer; `softmax` and the per-cell CE are computed when the graph has a softmax."""
+        named layer; `softmax` and the per-cell CE are computed when the graph has a softmax.
+        Without labels the pass is inference: the 16-bit paths then let a conv store its normalised output directly
+        (no pre-norm activation is kept, loss_backward is not possible); each value is rounded once from f32 there and
+        twice in the training form, so the two modes agree to a unit in the last place, not bit for bit."""
         net = self.net
         g = torch.as_tensor(grid)
         if g.dim() == 4:
@@ -366,12 +369,21 @@ class Engine(object):
                 a = n.attrs
                 src = n.inputs[0]
                 cin_pad = _pad(a["cin"], self.bke)
-                ops.conv_fwd([dict(x=P.view(src.name, cin_pad), w=self.w_fwd[n.name + "/weights"], cin=cin_pad,
-                                   kh=a["kh"], kw=a["kw"], dil=a["rate"])],
-                             P.a[n.name], n.channels, bias=self.params[n.name + "/biases"],
-                             relu=a.get("activation", "relu"), stats=P.stats[n.name])
-                ops.in_apply(P.a[n.name][..., :n.channels], P.stats[n.name], P.view(n.name, n.channels),
-                             bias=self.params[n.name + "/biases"], relu=a.get("activation", "relu"))
+                seg = [dict(x=P.view(src.name, cin_pad), w=self.w_fwd[n.name + "/weights"], cin=cin_pad,
+                            kh=a["kh"], kw=a["kw"], dil=a["rate"])]
+                bias, act = self.params[n.name + "/biases"], a.get("activation", "relu")
+                if labels is None and self.dt != F32 and P.view(n.name, n.channels).dtype == self.tdt:
+                    # inference: nobody reads the pre-norm activation afterwards, so the conv may store the normalised
+                    # output itself (a sample's tiles meet inside the launch; cutie_conv_in_fwd) - no in_apply pass
+                    if n.name not in P.sync_fw:
+                        P.sync_fw[n.name] = torch.zeros(ops.conv_sync_bytes(B, P.stats[n.name].shape[1], n.channels) // 4,
+                                                        dtype=torch.int32, device=self.dev)
+                    ops.conv_in_fwd(seg, P.a[n.name][..., :n.channels], P.view(n.name, n.channels), n.channels, bias, act,
+                                    P.stats[n.name], sync=P.sync_fw[n.name])
+                else:
+                    ops.conv_fwd(seg, P.a[n.name], n.channels, bias=bias, relu=act, stats=P.stats[n.name])
+                    ops.in_apply(P.a[n.name][..., :n.channels], P.stats[n.name], P.view(n.name, n.channels),
+                                 bias=bias, relu=act)
             elif n.op == "global_pool":
                 src = n.inputs[0]
                 ops.spatial_mean_bcast(P.view(src.name, src.channels), P.view(n.name, n.channels), P.pool_scratch)
@@ -413,7 +425,7 @@ class Engine(object):
         if ps_oob:
             raise CutieError("%d ps_1d_indices fall outside the image feature map (tf.batch_gather raises, "
                              "model_framework.py:83)" % ps_oob)
-        late = sum(int(s[0].item()) for s in P.sync.values()) if P.bwd_ready else 0
+        late = sum(int(s[0].item()) for s in list(P.sync.values()) + list(P.sync_fw.values()))
         if late:
             raise CutieError("%d conv tiles gave up waiting for their sample's other tiles (the GPU could not hold a "
                              "sample's workgroups at once): the gradients since the last check are invalid; set "

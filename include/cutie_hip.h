@@ -137,6 +137,22 @@ int cutie_conv_fwd(const cutie_conv_seg* segs /* host */, int n_segs,
                    const float* bias, int relu, float* stats, int stats_tiles,
                    int dtype, cutie_stream_t stream);
 
+/* Model.convolution as one call (model_framework.py:414-424): y = instance_norm(act(conv(x, W) + b)), i.e.
+ * cutie_conv_fwd into `a` followed by cutie_in_apply (K6 below) into `y`.  With a `sync` area (as for
+ * cutie_conv_dgrad_in_bwd below: cutie_conv_sync_bytes(B, stats_tiles, n_out) bytes, 64-byte aligned, zeroed ONCE, one
+ * per layer and shape, word 0 counts waits that ran out) and where the wide MFMA kernel applies and a sample's tiles
+ * are balanced, ONE launch does it: the tiles publish their moments as tagged granules, meet, and store y straight
+ * from the accumulators - `a` is then NOT written, so pass a `sync` area only when nobody needs `a` afterwards
+ * (inference; the backward pass reads it).  y is rounded once from the f32 activation in that form and from the stored
+ * 16-bit activation in the two-call form: equal to one unit in the last place, not bit for bit.  The choice depends on
+ * the layer and the grid shape only, never on the batch size.  `stats` is written either way. */
+int cutie_conv_in_fwd(const cutie_conv_seg* segs /* host */, int n_segs,
+                      int B, int H, int W, int n_out,
+                      void* a, int ld_a, void* y, int ld_y,
+                      const float* bias, int relu, float* stats, int stats_tiles, float eps,
+                      void* sync, size_t sync_bytes,
+                      int dtype, cutie_stream_t stream);
+
 /* The data gradient of a layer that ends in the instance norm of model_framework.py:423, together with the
  * first half of that norm's gradient: out = dy as cutie_conv_fwd(flip segments, no bias / activation) gives
  * it, and red[b][t][c] = (sum dy, sum dy*xhat) exactly as cutie_in_bwd_stats (K6 below) defines it for

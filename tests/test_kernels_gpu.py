@@ -411,6 +411,72 @@ def test_conv_dgrad_in_stats(ops, dt, case):
     assert torch.equal(dy, dy2) and torch.equal(red, red2)
 
 
+CONV_IN_FWD_CASES = [
+    # B, H, W, cin, cout, kh, kw, dil
+    (32, 64, 64, 64, 256, 3, 5, 1),      # the bench shape: 16 tiles a sample, two rounds of workgroups
+    (5, 64, 64, 64, 256, 3, 5, 4),       # grid not a multiple of 8: a sample's tiles spread over the XCDs
+    (3, 42, 63, 64, 128, 3, 5, 2),       # ragged tiles, channel tile 128
+    (4, 40, 64, 128, 64, 1, 1, 1),       # 1x1, channel tile 64
+    (2, 7, 80, 64, 512, 3, 5, 2),        # two channel tiles of 256
+    (8, 64, 64, 64, 256, 3, 5, 16),      # unbalanced tiles: the entry point takes the two-call form itself
+    (2, 12, 64, 64, 36, 3, 5, 1),        # not a wide-kernel shape: two-call form
+    (1, 160, 128, 64, 128, 3, 5, 1),     # 80 tiles a sample: plain block order
+]
+
+
+@pytest.mark.parametrize("dt", ["f16", "bf16", "f32"])
+@pytest.mark.parametrize("case", CONV_IN_FWD_CASES)
+def test_conv_in_fwd_one_launch_matches_the_two_call_form(ops, dt, case):
+    """cutie_conv_in_fwd with a sync area (one launch: a sample's tiles meet, y is stored, a is not) against the same
+    entry point without one (conv into a, then cutie_in_apply): the moments bit for bit, y to a unit in the last place
+    (rounded once from the f32 activation instead of from the stored 16-bit one) and against float64; a sample's y does
+    not depend on the batch it sits in.  Five launches on fresh data: a stale granule would show."""
+    B, H, W, cin, cout, kh, kw, dil = case
+    g = torch.Generator().manual_seed(hash(case) % 1000 + 11)
+    tdt = TDT[dt]
+    w = (torch.randn((kh, kw, cin, cout), generator=g) * 0.05).to(tdt).float()
+    bias = torch.randn(cout, generator=g) * 0.1
+    wf, _ = ops.pack_weights(w.to(DEV), CDT[dt], want_dgrad=False)
+    seg = lambda x: [dict(x=x, w=wf, cin=wf.shape[2], kh=kh, kw=kw, dil=dil)]
+    if wf.shape[2] != cin:
+        pytest.skip("padded cin")
+    T = ops.conv_stats_tiles(H, W)
+    ld = cout + 8
+    sync = torch.zeros(ops.conv_sync_bytes(B, T, cout) // 4, dtype=torch.int32, device=DEV)
+    bd = bias.to(DEV)
+    for it in range(5):
+        x = _rand_act(g, (B, H, W, cin), tdt).to(DEV)
+        a_ref = torch.zeros((B, H, W, ld), dtype=tdt, device=DEV)
+        y_ref = torch.full((B, H, W, ld), 3.0, dtype=tdt, device=DEV)
+        st_ref = torch.zeros((B, T, cout, 2), dtype=torch.float32, device=DEV)
+        ops.conv_in_fwd(seg(x), a_ref[..., :cout], y_ref[..., :cout], cout, bd, True, st_ref, sync=None)
+        a = torch.zeros((B, H, W, ld), dtype=tdt, device=DEV)
+        y = torch.full((B, H, W, ld), 3.0, dtype=tdt, device=DEV)
+        st = torch.zeros((B, T, cout, 2), dtype=torch.float32, device=DEV)
+        ops.conv_in_fwd(seg(x), a[..., :cout], y[..., :cout], cout, bd, True, st, sync=sync)
+        torch.cuda.synchronize()
+        assert int(sync[0]) == 0, "a tile's wait ran out"
+        assert torch.equal(st, st_ref), it
+        assert torch.all(y[..., cout:] == 3.0)
+        d = (y[..., :cout].float() - y_ref[..., :cout].float()).abs()
+        ulp = {"f16": 2.0 ** -10, "bf16": 2.0 ** -7, "f32": 1e-6}[dt]
+        assert float((d / (y_ref[..., :cout].float().abs() + 1.0)).max()) <= 1.01 * ulp, it
+    fused = int((sync[16:].view(torch.int64) >> 32).abs().sum()) > 0
+    if fused:
+        assert dt != "f32" and float(a.float().abs().max()) == 0.0       # the pre-norm activation was never written
+        # one sample alone gives the same bits as inside the batch
+        y1 = torch.zeros((1, H, W, ld), dtype=tdt, device=DEV)
+        s1 = torch.zeros(ops.conv_sync_bytes(1, T, cout) // 4, dtype=torch.int32, device=DEV)
+        ops.conv_in_fwd(seg(x[B - 1:]), torch.zeros_like(y1)[..., :cout], y1[..., :cout], cout, bd, True,
+                        torch.zeros((1, T, cout, 2), dtype=torch.float32, device=DEV), sync=s1)
+        assert torch.equal(y1[..., :cout], y[B - 1:, :, :, :cout])
+    else:
+        assert dt == "f32" or dil == 16 or cout == 36
+    z = co.conv_raw(x.double().cpu(), w.double(), dil) + bias.double()
+    ref = co.instance_norm(torch.relu(z))
+    assert relerr(y[..., :cout], ref) < {"f32": 1e-4, "f16": 3e-3, "bf16": 2e-2}[dt]
+
+
 DGRAD_BWD_CASES = [
     # B, H, W, channels of the consuming conv's output, channels of dy, dil, activation
     (32, 64, 64, 64, 256, 1, "relu"),    # the bench shape: 16 tiles a sample, a sample's tiles on one XCD, two rounds of workgroups
