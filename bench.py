@@ -46,16 +46,28 @@ def conv_launch_flops(segs, B, H, W, n_out):
 
 
 class ConvTimer(object):
-    """Wraps ops.conv_fwd and ops.conv_dgrad_in_bwd: brackets every forward / data-gradient conv launch with HIP
-    events on the launch stream.  A data gradient that also carries the instance-norm gradient (the one-launch form)
-    is timed as a whole and credited with the conv's FLOPs only; the two layers per step whose call falls back to the
-    two-call form (dilation 16) have the norm pass inside their bracket - the fraction reads low, never high."""
+    """Wraps ops.conv_fwd, ops.conv_in_fwd and ops.conv_dgrad_in_bwd: brackets every forward / data-gradient conv launch
+    with HIP events on the launch stream.  A launch that also carries the instance norm (forward) or its gradient (the
+    one-launch forms) is timed as a whole and credited with the conv's FLOPs only; the layers whose call falls back to
+    the two-call form (dilation 16) have the norm pass inside their bracket - the fraction reads low, never high."""
 
     def __init__(self, ops):
-        self.ops, self.orig, self.orig_bwd = ops, ops.conv_fwd, ops.conv_dgrad_in_bwd
+        self.ops, self.orig, self.orig_bwd, self.orig_in_fwd = ops, ops.conv_fwd, ops.conv_dgrad_in_bwd, ops.conv_in_fwd
         self.events, self.flops, self.enabled = [], [], False
         ops.conv_fwd = self
         ops.conv_dgrad_in_bwd = self.dgrad_in_bwd
+        ops.conv_in_fwd = self.in_fwd
+
+    def in_fwd(self, segs, a, y, n_out, *args, **kw):
+        if not self.enabled:
+            return self.orig_in_fwd(segs, a, y, n_out, *args, **kw)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        r = self.orig_in_fwd(segs, a, y, n_out, *args, **kw)
+        e1.record()
+        self.events.append((e0, e1))
+        self.flops.append(conv_launch_flops(segs, y.shape[0], y.shape[1], y.shape[2], n_out))
+        return r
 
     def dgrad_in_bwd(self, segs, dy, n_out, *a, **kw):
         if not self.enabled:
@@ -252,7 +264,7 @@ def main():
             traffic, traffic_src = pmc_traffic(args.dtype)
             out["roofline"] = {"bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
                                "frac": round(ach / peak, 4), "traffic": traffic, "traffic_source": traffic_src,
-                               "kernel": "conv_wide_kernel + conv_kernel (forward + data-gradient implicit GEMM)", "launches": n,
+                               "kernel": "conv_wide_kernel + conv_kernel (forward + data-gradient implicit GEMM, instance norm / its gradient inside the launch)", "launches": n,
                                "avg_launch_ms": round(ms / max(n, 1), 4),
                                "timed_steps": "every %d-th of the %d timed steps%s" % (
                                    ConvTimer.EVERY, args.steps,

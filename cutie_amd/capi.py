@@ -11,6 +11,7 @@ import threading
 import torch
 
 F32, BF16, F16 = 0, 1, 2
+ACT_FROM_Y = 16      # CUTIE_ACT_FROM_Y
 MAX_SEGS = 6
 REDUCE_SCRATCH = 1024
 
@@ -56,8 +57,8 @@ SIGNATURES = {
     "cutie_embed_bwd": (_i, [_vp, _i64, _vp, _i, _i, _vp, _i, _i, _vp, _sz, _vp]),
     "cutie_conv_stats_tiles": (_i, [_i, _i]),
     "cutie_conv_fwd": (_i, [_c.POINTER(ConvSeg), _i, _i, _i, _i, _i, _vp, _i, _i, _vp, _i, _vp, _i, _i, _vp]),
-    "cutie_conv_in_fwd": (_i, [_c.POINTER(ConvSeg), _i, _i, _i, _i, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _f, _vp, _sz, _i,
-                               _vp]),
+    "cutie_conv_in_fwd": (_i, [_c.POINTER(ConvSeg), _i, _i, _i, _i, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _f, _vp, _sz,
+                               _c.POINTER(_i), _i, _vp]),
     "cutie_conv_dgrad_in_stats": (_i, [_c.POINTER(ConvSeg), _i, _i, _i, _i, _i, _vp, _i, _i, _vp, _i, _i, _vp, _i, _f, _vp,
                                        _i, _vp, _i, _i, _vp]),
     "cutie_conv_sync_bytes": (_sz, [_i, _i, _i]),

@@ -115,6 +115,43 @@ __device__ __forceinline__ float norm_shift(const float* bias, int act, int c) {
     return act == 1 ? fmaxf(b, 0.f) : (act == 2 ? 1.f / (1.f + expf(-b)) : b);
 }
 
+// mean and 1/sigma of a (sample, channel) plane from its folded sums about shift.  Every kernel that needs them calls this
+// one function with contraction off: whether the compiler fuses a multiply into the next add would otherwise be its own
+// choice per call site, and the backward kernels must reproduce the forward launch's mean and 1/sigma BIT FOR BIT to
+// recognise y0 below.
+__device__ __forceinline__ void norm_mean_inv(float s1, float s2, float inv_n, float shift, float eps, float& mean, float& inv) {
+#pragma clang fp contract(off)
+    const float md = s1 * inv_n;                     // mean of (x - shift)
+    const float var = fmaxf(s2 * inv_n - md * md, 0.f);
+    mean = md + shift;
+    inv = rsqrtf(var + eps);
+}
+
+// The one-launch forward (cutie_conv_in_fwd) stores only y = (a - mean) * inv.  The ReLU pattern the backward pass needs
+// travels INSIDE y: every a == 0 element of a (sample, channel) plane holds exactly y0 = round16((0 - mean) * inv), and an
+// a > 0 element whose y rounds onto y0 is stored one unit in the last place above it (the forward stores y0_bits itself
+// into the a == 0 elements, it does not recompute them).  So mask = (bits of y != bits of y0),
+// exactly, with no second tensor.  y >= y0 always (rounding is monotone), so the bump moves y by at most one ulp.
+__device__ __forceinline__ unsigned short bits16(bf16_t v) { return v; }
+__device__ __forceinline__ unsigned short bits16(f16_t v) { return __builtin_bit_cast(unsigned short, v); }
+__device__ __forceinline__ unsigned short next_up16(unsigned short u) {      // the next 16-bit float above u (same for f16 / bf16)
+    if (u == 0x8000u) return 0x0001u;              // -0 -> smallest positive
+    return (u & 0x8000u) ? (unsigned short)(u - 1u) : (unsigned short)(u + 1u);
+}
+template <typename T> __device__ __forceinline__ unsigned short y0_bits(float mean, float inv) {
+#pragma clang fp contract(off)
+    float y0 = (0.f - mean) * inv;
+    // the product must exist as an f32 value before it is narrowed: left alone the compiler narrows straight out of the
+    // multiplier in some kernels (v_fma_mixlo_f16, one rounding) and not in others (two roundings) - one unit apart when
+    // the product sits next to a tie
+    asm volatile("" : "+v"(y0));
+    T t;
+    store_from_f32(&t, y0);
+    const unsigned short u = bits16(t);
+    return u == 0x8000u ? (unsigned short)0 : u;      // one zero: the compiler may turn 0 - mean into a negation
+}
+template <> __device__ __forceinline__ unsigned short y0_bits<float>(float, float) { return 0; }      // f32 path never stores y only
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -872,14 +872,14 @@ static int conv_fwd_impl(const cutie_conv_seg* segs, int n_segs, int B, int H, i
                 q.bw_eps = nb->eps; q.bw_red = nb->red; q.bw_red_tiles = nb->red_tiles; q.bw_bias = nb->bias; q.bw_act = nb->act;
                 // the whole norm gradient inside this launch: a sample's tiles meet after publishing their sums
                 int plain = 0;
-                meet = nb->dz && nb->sync && cutie::config().rendezvous && nb->relu != 2 && (nb->ld_dz * 2) % 16 == 0 &&
+                meet = nb->dz && nb->sync && cutie::config().rendezvous && (nb->relu & 15) != 2 && (nb->ld_dz * 2) % 16 == 0 &&
                        cutie::aligned16(nb->dz) && (!nb->dbias || q.tiles_h * q.tiles_w <= nb->dbias_tiles) &&
                        cutie::conv_wide_rendezvous_ok(q, bn, &plain);
                 if (meet) {
                     q.rv_err = reinterpret_cast<int*>(nb->sync);      // word 0: timeouts; the granules start 64 bytes in
                     q.rv_slots = reinterpret_cast<unsigned long long*>(nb->sync + 16);
                     q.rv_dz = (char*)nb->dz; q.rv_ld_dz = nb->ld_dz; q.rv_dbias = nb->dbias; q.rv_dbias_tiles = nb->dbias_tiles;
-                    q.rv_relu = nb->relu; q.rv_plain_order = plain; q.rv_nowait = cutie::config().rv_nowait ? 1 : 0;
+                    q.rv_relu = nb->relu & 15; q.rv_plain_order = plain; q.rv_nowait = cutie::config().rv_nowait ? 1 : 0;
                 }
             }
             if (nf && !nb && stats && cutie::config().rendezvous && relu != 2 && (nf->ld_y * 2) % 16 == 0 && cutie::aligned16(nf->y)) {
@@ -927,8 +927,9 @@ extern "C" int cutie_conv_fwd(const cutie_conv_seg* segs, int n_segs, int B, int
 
 extern "C" int cutie_conv_in_fwd(const cutie_conv_seg* segs, int n_segs, int B, int H, int W, int n_out, void* a, int ld_a,
                                  void* y, int ld_y, const float* bias, int relu, float* stats, int stats_tiles, float eps,
-                                 void* sync, size_t sync_bytes, int dtype, cutie_stream_t stream_) {
+                                 void* sync, size_t sync_bytes, int* fused, int dtype, cutie_stream_t stream_) {
     CUTIE_CHECK_ARG(B >= 0 && H >= 1 && W >= 1 && n_out >= 1, "conv_in_fwd: bad sizes");
+    if (fused) *fused = 0;
     if (B == 0) return CUTIE_OK;
     CUTIE_CHECK_ARG(a && y && stats && ld_a >= n_out && ld_y >= n_out, "conv_in_fwd: null pointer or leading dimension < n_out");
     if (sync && (sync_bytes < cutie_conv_sync_bytes(B, stats_tiles, n_out) || (reinterpret_cast<uintptr_t>(sync) & 63))) {
@@ -939,7 +940,10 @@ extern "C" int cutie_conv_in_fwd(const cutie_conv_seg* segs, int n_segs, int B, 
     const NormFwd nf = {y, ld_y, eps, (unsigned*)sync};
     const int rc = conv_fwd_impl(segs, n_segs, B, H, W, n_out, a, ld_a, dtype, bias, relu, stats, stats_tiles, dtype, nullptr,
                                  stream_, sync ? &nf : nullptr);
-    if (rc == 1) return CUTIE_OK;      // one launch did all of it; `a` was not written
+    if (rc == 1) {      // one launch did all of it; `a` was not written
+        if (fused) *fused = 1;
+        return CUTIE_OK;
+    }
     if (rc != CUTIE_OK) return rc;
     return cutie_in_apply(a, ld_a, dtype, stats, stats_tiles, eps, y, ld_y, dtype, B, H * W, n_out, bias, relu, stream_);
 }
@@ -975,7 +979,7 @@ extern "C" int cutie_conv_dgrad_in_bwd(const cutie_conv_seg* segs, int n_segs, i
     if (B == 0) return CUTIE_OK;
     CUTIE_CHECK_ARG(dy && a && stats && red && dz && ld_dy >= n_out && ld_a >= n_out && ld_dz >= n_out,
                     "conv_dgrad_in_bwd: null pointer or leading dimension < n_out");
-    CUTIE_CHECK_ARG(relu >= 0 && relu <= 2, "conv_dgrad_in_bwd: activation code %d", relu);
+    CUTIE_CHECK_ARG((relu & 15) <= 2 && (relu & ~(15 | CUTIE_ACT_FROM_Y)) == 0 && relu >= 0, "conv_dgrad_in_bwd: activation code %d", relu);
     CUTIE_CHECK_ARG(stats_tiles >= 1 && red_tiles >= cutie_conv_stats_tiles(H, W) && red_tiles <= 65535,
                     "conv_dgrad_in_bwd: stats_tiles=%d, red_tiles=%d (>= cutie_conv_stats_tiles(%d, %d) = %d)", stats_tiles,
                     red_tiles, H, W, cutie_conv_stats_tiles(H, W));

@@ -41,6 +41,11 @@ template <int BN> struct Shape {
     static constexpr int LDS = (CW_B0 + 2 * BBUF > TAB + 2 * BN * 4) ? CW_B0 + 2 * BBUF : TAB + 2 * BN * 4;
 };
 
+__device__ __forceinline__ unsigned short u16_of(const uint4& u, int e) {      // e-th 16-bit element of a 16-byte piece
+    const unsigned c = e < 2 ? u.x : (e < 4 ? u.y : (e < 6 ? u.z : u.w));
+    return (unsigned short)((e & 1) ? (c >> 16) : (c & 0xffffu));
+}
+
 template <int DT> __device__ __forceinline__ void unpack8(const uint4& u, float* v) {
     if constexpr (DT == CUTIE_BF16) {
         v[0] = __uint_as_float(u.x << 16); v[1] = __uint_as_float(u.x & 0xffff0000u);
@@ -163,10 +168,9 @@ __device__ __forceinline__ void conv_wide_epilogue(const ConvParams& p, float4_t
     float* tab = reinterpret_cast<float*>(smem + S::TAB);       // [2][BN]
     if (bw && tid < BN) {
         const float inv_n = 1.f / (float)(H * W);
-        const float md = fs * inv_n;             // the moments are kept about act(bias): norm.hip's fold_slots<1>
-        const float var = fmaxf(fss * inv_n - md * md, 0.f);
-        tab[tid] = md + (n0 + tid < n_out ? norm_shift(p.bw_bias, p.bw_act, n0 + tid) : 0.f);
-        tab[BN + tid] = rsqrtf(var + p.bw_eps);
+        // the moments are kept about act(bias): norm.hip's fold_slots<1>
+        norm_mean_inv(fs, fss, inv_n, n0 + tid < n_out ? norm_shift(p.bw_bias, p.bw_act & 15, n0 + tid) : 0.f, p.bw_eps,
+                      tab[tid], tab[BN + tid]);
     }
 #pragma unroll
     for (int n = 0; n < 4; ++n) {
@@ -218,11 +222,7 @@ __device__ __forceinline__ void conv_wide_epilogue(const ConvParams& p, float4_t
             float r1, r2;
             granule_sweep(p.fw_slots, b, p.stats_tiles, p.tiles_h * p.tiles_w, n_out, n0 + tid, fw_tag, p.rv_nowait, p.rv_err, r1, r2);
             const float inv_n = 1.f / (float)(H * W);
-            const float md = r1 * inv_n;
-            const float var = fmaxf(r2 * inv_n - md * md, 0.f);
-            const float bvv = p.bias ? p.bias[n0 + tid] : 0.f;
-            tab[tid] = md + (p.relu ? fmaxf(bvv, 0.f) : bvv);
-            tab[BN + tid] = rsqrtf(var + p.fw_eps);
+            norm_mean_inv(r1, r2, inv_n, norm_shift(p.bias, p.relu, n0 + tid), p.fw_eps, tab[tid], tab[BN + tid]);
         }
     }
     if (fw) {
@@ -231,23 +231,36 @@ __device__ __forceinline__ void conv_wide_epilogue(const ConvParams& p, float4_t
         for (int n = 0; n < 4; ++n) {
             const int cl = wn * 64 + n * 16 + li;
             const float mean = tab[cl], inv = tab[BN + cl];
+            const unsigned short y0 = y0_bits<TO>(mean, inv);
 #pragma unroll
             for (int m = 0; m < S::MB; ++m) {
                 const int mb = wm * S::MB + m;
 #pragma unroll
-                for (int r = 0; r < 4; ++r)      // y = (a - mean) * inv from the UNROUNDED activation: one rounding
-                    store_from_f32(Cs + (mb * 16 + lg * 4 + r) * BN + cl, (acc[m][n][r] - mean) * inv);
+                for (int r = 0; r < 4; ++r) {    // y = (a - mean) * inv from the UNROUNDED activation: one rounding
+                    const float v = acc[m][n][r];
+                    TO yh;
+                    store_from_f32(&yh, (v - mean) * inv);
+                    // the ReLU pattern travels inside y (common.h): an active element never holds y0's bits
+                    if (p.relu) {
+                        if (!(v > 0.f)) yh = __builtin_bit_cast(TO, y0);
+                        else if (bits16(yh) == y0) yh = __builtin_bit_cast(TO, next_up16(y0));
+                    }
+                    Cs[(mb * 16 + lg * 4 + r) * BN + cl] = yh;
+                }
             }
         }
         __syncthreads();
     }
     const int col = n0 + pc * 8;
     float mean8[8], inv8[8], g1[8], g2[8];
+    const bool from_y = bw && (p.bw_act & CUTIE_ACT_FROM_Y);      // bw_a is the layer's normalised output: xhat = y
+    unsigned short y0b[8];
     if (bw) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             mean8[e] = tab[pc * 8 + e];
             inv8[e] = tab[BN + pc * 8 + e];
+            y0b[e] = y0_bits<TO>(mean8[e], inv8[e]);
             g1[e] = 0.f;
             g2[e] = 0.f;
         }
@@ -273,7 +286,7 @@ __device__ __forceinline__ void conv_wide_epilogue(const ConvParams& p, float4_t
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     g1[e] += g[e];
-                    g2[e] += g[e] * ((x[e] - mean8[e]) * inv8[e]);
+                    g2[e] += g[e] * (from_y ? x[e] : (x[e] - mean8[e]) * inv8[e]);
                 }
             }
         }
@@ -333,9 +346,12 @@ __device__ __forceinline__ void conv_wide_epilogue(const ConvParams& p, float4_t
                 TO o[8];
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {     // the arithmetic of in_bwd_apply_kernel, operation for operation
-                    const float xh = (x[e] - mean8[e]) * inv8[e];
+                    const float xh = from_y ? x[e] : (x[e] - mean8[e]) * inv8[e];
                     float d = inv8[e] * (g[e] - m1[e] - xh * m2[e]);
-                    if (p.rv_relu == 1 && !(x[e] > 0.f)) d = 0.f;
+                    if (p.rv_relu == 1) {
+                        const bool active = from_y ? (u16_of(av[k], e) != y0b[e]) : (x[e] > 0.f);
+                        if (!active) d = 0.f;
+                    }
                     sb[e] += d;
                     store_from_f32(&o[e], d);
                 }

@@ -128,10 +128,7 @@ __device__ __forceinline__ void fold_slots(const float* p, int b, int T, int C, 
         float s, ss;
         sum_tiles(p, b, T, C, c, s, ss);
         if (MODE == 1) {
-            const float md = s * inv_n;          // mean of (x - shift)
-            const float var = fmaxf(ss * inv_n - md * md, 0.f);
-            s = md + norm_shift(bias, act, c);
-            ss = rsqrtf(var + eps);
+            norm_mean_inv(s, ss, inv_n, norm_shift(bias, act, c), eps, s, ss);
         }
         t0[c] = s;
         t1[c] = ss;
@@ -210,7 +207,8 @@ __global__ __launch_bounds__(256) void in_bwd_stats_kernel(const TD* __restrict_
     extern __shared__ float tab[];      // [2][C]
     const int CV = C / VEC;
     const Map m = make_map(HW, CV);
-    fold_slots<1>(stats, m.b, st, C, 1.f / (float)HW, eps, tab, tab + C, bias, act);
+    fold_slots<1>(stats, m.b, st, C, 1.f / (float)HW, eps, tab, tab + C, bias, act & 15);
+    const bool from_y = act & CUTIE_ACT_FROM_Y;      // `a` is the normalised output: xhat = y
     __syncthreads();
     float s1[VEC] = {}, s2[VEC] = {};
     if (m.active) {
@@ -225,7 +223,7 @@ __global__ __launch_bounds__(256) void in_bwd_stats_kernel(const TD* __restrict_
 #pragma unroll
             for (int e = 0; e < VEC; ++e) {
                 s1[e] += g.v[e];
-                s2[e] += g.v[e] * ((x.v[e] - mean[e]) * inv[e]);
+                s2[e] += g.v[e] * (from_y ? x.v[e] : (x.v[e] - mean[e]) * inv[e]);
             }
         }
     }
@@ -248,12 +246,15 @@ __global__ __launch_bounds__(256) void in_bwd_apply_kernel(const TD* __restrict_
     const int CV = C / VEC;
     const Map m = make_map(HW, CV);
     const float inv_n = 1.f / (float)HW;
+    const bool from_y = relu & CUTIE_ACT_FROM_Y;      // `a` is the normalised output with the ReLU pattern inside (common.h)
+    relu &= 15;
     fold_slots<1>(stats, m.b, st, C, inv_n, eps, tab, tab + C, bias, relu);
     fold_slots<0>(redin, m.b, rt, C, inv_n, eps, tab + 2 * C, tab + 3 * C);
     __syncthreads();
     float sb[VEC] = {};
     if (m.active) {
         float mean[VEC], inv[VEC], m1[VEC], m2[VEC];
+        unsigned short y0b[VEC];
 #pragma unroll
         for (int e = 0; e < VEC; ++e) {
             const int c = m.cl * VEC + e;
@@ -261,6 +262,7 @@ __global__ __launch_bounds__(256) void in_bwd_apply_kernel(const TD* __restrict_
             inv[e] = tab[C + c];
             m1[e] = tab[2 * C + c] * inv_n;
             m2[e] = tab[3 * C + c] * inv_n;
+            y0b[e] = y0_bits<TA>(mean[e], inv[e]);
         }
 #pragma unroll 4
         for (int hw = m.hw0 + m.sub; hw < m.hw1; hw += m.rows_par) {
@@ -270,10 +272,18 @@ __global__ __launch_bounds__(256) void in_bwd_apply_kernel(const TD* __restrict_
             vecf<VEC> o;
 #pragma unroll
             for (int e = 0; e < VEC; ++e) {
-                const float xh = (x.v[e] - mean[e]) * inv[e];
+                const float xh = from_y ? x.v[e] : (x.v[e] - mean[e]) * inv[e];
                 float d = inv[e] * (g.v[e] - m1[e] - xh * m2[e]);
                 if (relu == 1) {
-                    if (!(x.v[e] > 0.f)) d = 0.f;
+                    bool active = x.v[e] > 0.f;
+                    if (from_y) {
+                        if constexpr (sizeof(TA) == 2) {      // x came out of a 16-bit value: rounding it back is exact
+                            TA t;
+                            store_from_f32(&t, x.v[e]);
+                            active = bits16(t) != y0b[e];
+                        }
+                    }
+                    if (!active) d = 0.f;
                 } else if (relu == 2) {
                     d *= x.v[e] * (1.f - x.v[e]);      // sigmoid': a is the stored sigmoid output
                 }
@@ -460,6 +470,8 @@ extern "C" int cutie_in_bwd_apply(const void* dy, int ld_dy, int dy_dtype, const
     CUTIE_CHECK_ARG(dy && a && stats && red && dz && ld_dy >= C && ld_a >= C && ld_dz >= C,
                     "in_bwd_apply: null pointer or ld < C");
     CUTIE_CHECK_ARG(a_dtype == dz_dtype, "in_bwd_apply: dz dtype must equal a dtype");
+    CUTIE_CHECK_ARG(!(relu & CUTIE_ACT_FROM_Y) || (a_dtype != CUTIE_F32 && (relu & 15) != 2),
+                    "in_bwd_apply: CUTIE_ACT_FROM_Y goes with a 16-bit y and no sigmoid");
     CUTIE_CHECK_ARG(stats_tiles >= 1 && red_tiles >= 1 && (!dbias || (dbias_tiles >= 1 && dbias_tiles <= 65535)),
                     "in_bwd_apply: tiles %d / %d / %d", stats_tiles, red_tiles, dbias_tiles);
     const dim3 g = dbias ? dim3(dbias_tiles, B) : reduce_grid(B, HW, C, vec);

@@ -14,6 +14,12 @@ IN_EPS = 1e-6  # tf.contrib.layers.instance_norm default epsilon (model_framewor
 ACTIVATION_CODE = {None: 0, False: 0, "none": 0, True: 1, "relu": 1, "sigmoid": 2}
 
 
+def _act(relu, from_y=False):
+    """activation code; from_y: the `a` operand of a backward function is the layer's normalised output as the one-launch
+    forward stores it (CUTIE_ACT_FROM_Y)"""
+    return ACTIVATION_CODE[relu] | (capi.ACT_FROM_Y if from_y else 0)
+
+
 def _bke(dt):
     return 32 if dt == F32 else 64
 
@@ -168,18 +174,21 @@ def conv_sync_bytes(B, red_tiles, n_out):
 def conv_in_fwd(segs, a, y, n_out, bias, relu, stats, sync=None, eps=IN_EPS):
     """conv + bias + activation + instance norm as one call (cutie_conv_in_fwd): a = scratch view for the pre-norm
     activation, y = output view, stats as conv_fwd.  With `sync` (int32 tensor of conv_sync_bytes(B, T, n_out) bytes, zeroed
-    once, dedicated to this layer and shape) the launch may store y directly and leave `a` unwritten (inference)."""
+    once, dedicated to this layer and shape) the launch may store y directly and leave `a` unwritten; returns True when it
+    did - the backward functions then take y in place of a with from_y=True."""
     B = y.shape[0]
     arr, dt = _seg_array(segs, y, n_out, "conv_in_fwd")
     if dt_of(a) != dt or dt_of(y) != dt:
         raise capi.CutieError("conv_in_fwd: a and y must have the segments' dtype")
+    fused = ctypes.c_int(0)
     call("cutie_conv_in_fwd", arr, len(segs), B, y.shape[1], y.shape[2], n_out, ptr(a), ld_of(a), ptr(y), ld_of(y), ptr(bias),
          ACTIVATION_CODE[relu], ptr(stats), _tiles(stats, B, n_out, True), eps, ptr(sync),
-         sync.numel() * sync.element_size() if sync is not None else 0, dt, stream())
-    return y
+         sync.numel() * sync.element_size() if sync is not None else 0, ctypes.byref(fused), dt, stream())
+    return bool(fused.value)
 
 
-def conv_dgrad_in_bwd(segs, dy, n_out, a, stats, red, dz, dbias_part=None, relu=True, sync=None, eps=IN_EPS, bias=None):
+def conv_dgrad_in_bwd(segs, dy, n_out, a, stats, red, dz, dbias_part=None, relu=True, sync=None, eps=IN_EPS, bias=None,
+                      from_y=False):
     """Data gradient of an instance-normalised layer and the gradient of its norm + activation in one call
     (cutie_conv_dgrad_in_bwd): segs as conv_fwd (flip=True), dy = scratch view [B,H,W,>=n_out], a / stats = the layer's
     forward activation and moments, red = f32 [B,T,n_out,2] zeroed once, dz = output view, dbias_part f32 [B*T', n_out],
@@ -191,7 +200,7 @@ def conv_dgrad_in_bwd(segs, dy, n_out, a, stats, red, dz, dbias_part=None, relu=
     if dt_of(dy) != dt or dt_of(a) != dt or dt_of(dz) != dt:
         raise capi.CutieError("conv_dgrad_in_bwd: dy, a and dz must have the segments' dtype")
     call("cutie_conv_dgrad_in_bwd", arr, len(segs), B, dy.shape[1], dy.shape[2], n_out, ptr(dy), ld_of(dy), ptr(a), ld_of(a),
-         ptr(stats), _tiles(stats, B, n_out, True), eps, ptr(red), _tiles(red, B, n_out, True), ACTIVATION_CODE[relu],
+         ptr(stats), _tiles(stats, B, n_out, True), eps, ptr(red), _tiles(red, B, n_out, True), _act(relu, from_y),
          ptr(bias), ptr(dz), ld_of(dz), ptr(dbias_part), _tiles(dbias_part, B, n_out, False), ptr(sync),
          sync.numel() * sync.element_size() if sync is not None else 0, dt, stream())
     return dz
@@ -295,19 +304,19 @@ def in_apply(a, stats, y, eps=IN_EPS, bias=None, relu=None):
     return y
 
 
-def in_bwd_stats(dy, a, stats, red, eps=IN_EPS, bias=None, relu=None):
+def in_bwd_stats(dy, a, stats, red, eps=IN_EPS, bias=None, relu=None, from_y=False):
     B, HW, C = _bhwc(a)
     call("cutie_in_bwd_stats", ptr(dy), ld_of(dy), dt_of(dy), ptr(a), ld_of(a), dt_of(a), ptr(stats),
-         _tiles(stats, B, C, True), eps, ptr(red), _tiles(red, B, C, True), B, HW, C, ptr(bias), ACTIVATION_CODE[relu],
+         _tiles(stats, B, C, True), eps, ptr(red), _tiles(red, B, C, True), B, HW, C, ptr(bias), _act(relu, from_y),
          stream())
     return red
 
 
-def in_bwd_apply(dy, a, stats, red, dz, dbias_part=None, relu=True, eps=IN_EPS, bias=None):
+def in_bwd_apply(dy, a, stats, red, dz, dbias_part=None, relu=True, eps=IN_EPS, bias=None, from_y=False):
     """dbias_part: f32 [B * T, C] partial sums, one row per (sample, slice of H*W) (fold with sum_rows)."""
     B, HW, C = _bhwc(a)
     call("cutie_in_bwd_apply", ptr(dy), ld_of(dy), dt_of(dy), ptr(a), ld_of(a), dt_of(a), ptr(stats),
-         _tiles(stats, B, C, True), eps, ptr(red), _tiles(red, B, C, True), ACTIVATION_CODE[relu], ptr(dz), ld_of(dz),
+         _tiles(stats, B, C, True), eps, ptr(red), _tiles(red, B, C, True), _act(relu, from_y), ptr(dz), ld_of(dz),
          dt_of(dz), ptr(dbias_part), _tiles(dbias_part, B, C, False), B, HW, C, ptr(bias), stream())
     return dz
 

@@ -203,7 +203,7 @@ class Engine(object):
         tiles = {n.name: ops.conv_stats_tiles(*spatial(n)) for n in convs}
         n_stats = sum(B * tiles[n.name] * n.channels * 2 for n in convs)
         P.stats_all = torch.zeros(n_stats, dtype=torch.float32, device=dev)
-        P.a, P.stats, P.red, P.dz, P.dy, P.dbpart, P.sync, P.sync_fw = {}, {}, {}, {}, {}, {}, {}, {}
+        P.a, P.stats, P.red, P.dz, P.dy, P.dbpart, P.sync, P.sync_fw, P.fused = {}, {}, {}, {}, {}, {}, {}, {}, {}
         so = 0
         for n in convs:
             hs, ws = spatial(n)
@@ -304,6 +304,38 @@ class Engine(object):
         walk(name, 0)
         return segs
 
+    # CUTIE_TRAIN_FWD_FUSED=0: training keeps the pre-norm activation (conv, then in_apply), as inference did before
+    train_fwd_fused = os.environ.get("CUTIE_TRAIN_FWD_FUSED", "1") != "0"
+
+    def _act_operand(self, P, n):
+        """what the backward kernels read as layer n's forward activation: the pre-norm activation a, or - where the
+        forward launch stored the normalised output only - y itself (xhat = y, ReLU pattern inside y)"""
+        if P.fused.get(n.name):
+            return P.view(n.name, n.channels), True
+        return P.a[n.name][..., :n.channels], False
+
+    def relu_mask(self, P, name):
+        """bool [B,H,W,C]: where layer `name`'s activation is non-zero in the last forward pass (the pattern the
+        backward pass uses).  From a where it was stored; where only y was, from y's encoding: the a == 0 elements of a
+        (sample, channel) plane all hold the plane's smallest value y0 = round16((0 - mean) * inv)."""
+        n = self.net.layers[name]
+        if not P.fused.get(name):
+            return P.a[name][..., :n.channels] > 0
+        y = P.view(name, n.channels).float()
+        st = P.stats[name].double().sum(dim=1)                               # [B, C, 2], about shift = act(bias)
+        hw = y.shape[1] * y.shape[2]
+        bias = self.params[name + "/biases"].double()
+        act = n.attrs.get("activation", "relu")
+        shift = torch.relu(bias) if act == "relu" else bias
+        md = st[..., 0] / hw
+        mean = md + shift
+        inv = torch.rsqrt((st[..., 1] / hw - md * md).clamp_min(0) + ops.IN_EPS)
+        y0 = ((0.0 - mean) * inv).float()[:, None, None, :]                  # the device rounds this to 16 bits
+        ymin = y.amin(dim=(1, 2), keepdim=True)
+        ulp = 2.0 ** (-10 if self.dt == F16 else -7)
+        has_zero = (ymin - y0).abs() <= 2 * ulp * (y0.abs() + 1e-3)          # the plane's minimum IS y0: some a == 0
+        return ~((y == ymin) & has_zero)
+
     def _sampler_consumers(self, P, name):
         """positional_sampling nodes that gather from tensor `name` (their input 0)"""
         return [c for c in P.consumers.get(name, []) if c.op == "positional_sampling" and c.inputs[0].name == name]
@@ -327,10 +359,11 @@ class Engine(object):
             ops.convert(acc.view(P.B, P.Hi, P.W, C), P.dy[n.name][..., :C])
         elif segs:
             if n.op == "conv":
-                ops.conv_dgrad_in_bwd(segs, P.dy[n.name][..., :n.channels], n.channels, P.a[n.name][..., :n.channels],
+                av, from_y = self._act_operand(P, n)
+                ops.conv_dgrad_in_bwd(segs, P.dy[n.name][..., :n.channels], n.channels, av,
                                       P.stats[n.name], P.red[n.name], P.dz[n.name][..., :n.channels],
                                       dbias_part=P.dbpart[n.name], relu=n.attrs.get("activation", "relu"),
-                                      sync=P.sync[n.name], bias=self.params[n.name + "/biases"])
+                                      sync=P.sync[n.name], bias=self.params[n.name + "/biases"], from_y=from_y)
                 return True
             ops.conv_fwd(segs, P.dy[n.name], n.channels)
         return False
@@ -372,15 +405,18 @@ class Engine(object):
                 seg = [dict(x=P.view(src.name, cin_pad), w=self.w_fwd[n.name + "/weights"], cin=cin_pad,
                             kh=a["kh"], kw=a["kw"], dil=a["rate"])]
                 bias, act = self.params[n.name + "/biases"], a.get("activation", "relu")
-                if labels is None and self.dt != F32 and P.view(n.name, n.channels).dtype == self.tdt:
-                    # inference: nobody reads the pre-norm activation afterwards, so the conv may store the normalised
-                    # output itself (a sample's tiles meet inside the launch; cutie_conv_in_fwd) - no in_apply pass
+                if self.dt != F32 and P.view(n.name, n.channels).dtype == self.tdt and (
+                        labels is None or (act != "sigmoid" and self.train_fwd_fused)):
+                    # the conv may store the normalised output itself (a sample's tiles meet inside the launch;
+                    # cutie_conv_in_fwd): no in_apply pass, and no pre-norm activation - the backward pass then takes
+                    # xhat = y and reads the ReLU pattern out of y (P.fused)
                     if n.name not in P.sync_fw:
                         P.sync_fw[n.name] = torch.zeros(ops.conv_sync_bytes(B, P.stats[n.name].shape[1], n.channels) // 4,
                                                         dtype=torch.int32, device=self.dev)
-                    ops.conv_in_fwd(seg, P.a[n.name][..., :n.channels], P.view(n.name, n.channels), n.channels, bias, act,
-                                    P.stats[n.name], sync=P.sync_fw[n.name])
+                    P.fused[n.name] = ops.conv_in_fwd(seg, P.a[n.name][..., :n.channels], P.view(n.name, n.channels),
+                                                      n.channels, bias, act, P.stats[n.name], sync=P.sync_fw[n.name])
                 else:
+                    P.fused[n.name] = False
                     ops.conv_fwd(seg, P.a[n.name], n.channels, bias=bias, relu=act, stats=P.stats[n.name])
                     ops.in_apply(P.a[n.name][..., :n.channels], P.stats[n.name], P.view(n.name, n.channels),
                                  bias=bias, relu=act)
@@ -487,11 +523,11 @@ class Engine(object):
                 have_dz = self._backprop_into(P, n) if n.name != lname else False
                 if not have_dz:
                     dy = P.dy[n.name][..., :n.channels]
-                    av = P.a[n.name][..., :n.channels]
+                    av, from_y = self._act_operand(P, n)
                     bias, act = self.params[n.name + "/biases"], a.get("activation", "relu")
-                    ops.in_bwd_stats(dy, av, P.stats[n.name], P.red[n.name], bias=bias, relu=act)
+                    ops.in_bwd_stats(dy, av, P.stats[n.name], P.red[n.name], bias=bias, relu=act, from_y=from_y)
                     ops.in_bwd_apply(dy, av, P.stats[n.name], P.red[n.name], P.dz[n.name][..., :n.channels],
-                                     dbias_part=P.dbpart[n.name], relu=act, bias=bias)
+                                     dbias_part=P.dbpart[n.name], relu=act, bias=bias, from_y=from_y)
                 src = n.inputs[0]
                 if side is not None:
                     # dz of this layer is final: its weight gradient (and, data-parallel, the L2 term and the

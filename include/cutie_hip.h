@@ -39,6 +39,11 @@ extern "C" {
 
 #define CUTIE_MAX_SEGS 6
 
+/* Activation codes: 0 none, 1 ReLU, 2 sigmoid.  Backward entry points that take a layer's forward activation `a` accept
+ * the code OR-ed with CUTIE_ACT_FROM_Y: the operand is then the layer's NORMALISED output y as the one-launch form of
+ * cutie_conv_in_fwd stores it (xhat = y; the ReLU pattern is read out of y, see that entry point). */
+#define CUTIE_ACT_FROM_Y 16
+
 typedef void* cutie_stream_t; /* hipStream_t */
 
 int cutie_version(void);
@@ -143,14 +148,17 @@ int cutie_conv_fwd(const cutie_conv_seg* segs /* host */, int n_segs,
  * per layer and shape, word 0 counts waits that ran out) and where the wide MFMA kernel applies and a sample's tiles
  * are balanced, ONE launch does it: the tiles publish their moments as tagged granules, meet, and store y straight
  * from the accumulators - `a` is then NOT written, so pass a `sync` area only when nobody needs `a` afterwards
- * (inference; the backward pass reads it).  y is rounded once from the f32 activation in that form and from the stored
- * 16-bit activation in the two-call form: equal to one unit in the last place, not bit for bit.  The choice depends on
- * the layer and the grid shape only, never on the batch size.  `stats` is written either way. */
+ * unless the backward entry points are then given y with CUTIE_ACT_FROM_Y.  *fused (host int, nullable) receives 1
+ * when the one-launch form ran, else 0.  y is rounded once from the f32 activation in that form and from the stored
+ * 16-bit activation in the two-call form: equal to one unit in the last place, not bit for bit.  In the one-launch form y
+ * also carries the ReLU pattern: every a == 0 element of a (sample, channel) plane holds exactly
+ * y0 = round16((0 - mean) * inv), and an a > 0 element whose y rounds onto y0 is stored one ulp above it.  The choice
+ * depends on the layer and the grid shape only, never on the batch size.  `stats` is written either way. */
 int cutie_conv_in_fwd(const cutie_conv_seg* segs /* host */, int n_segs,
                       int B, int H, int W, int n_out,
                       void* a, int ld_a, void* y, int ld_y,
                       const float* bias, int relu, float* stats, int stats_tiles, float eps,
-                      void* sync, size_t sync_bytes,
+                      void* sync, size_t sync_bytes, int* fused /* host, nullable */,
                       int dtype, cutie_stream_t stream);
 
 /* The data gradient of a layer that ends in the instance norm of model_framework.py:423, together with the

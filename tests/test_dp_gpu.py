@@ -88,12 +88,12 @@ def test_forward_is_bit_reproducible_and_backward_nearly():
     grid, labels = _inputs(42)
     P = eng.forward(grid, labels=labels)
     logits = eng.get(P, "cls_logits").clone()
-    a8 = P.a["encoder1_8"].clone()
+    a8 = eng.relu_mask(P, "encoder1_8").clone()
     eng.loss_backward(P)
     g1 = eng.grads_flat.clone()
     for _ in range(3):
         P = eng.forward(grid, labels=labels)
-        assert torch.equal(eng.get(P, "cls_logits"), logits) and torch.equal(P.a["encoder1_8"], a8)
+        assert torch.equal(eng.get(P, "cls_logits"), logits) and torch.equal(eng.relu_mask(P, "encoder1_8"), a8)
         eng.loss_backward(P)
         dense = slice(0, eng.n_dense)
         assert torch.equal(eng.grads_flat[dense], g1[dense])              # conv kernels and biases: bit-identical

@@ -460,7 +460,7 @@ def test_conv_in_fwd_one_launch_matches_the_two_call_form(ops, dt, case):
         assert torch.all(y[..., cout:] == 3.0)
         d = (y[..., :cout].float() - y_ref[..., :cout].float()).abs()
         ulp = {"f16": 2.0 ** -10, "bf16": 2.0 ** -7, "f32": 1e-6}[dt]
-        assert float((d / (y_ref[..., :cout].float().abs() + 1.0)).max()) <= 1.01 * ulp, it
+        assert float((d / (y_ref[..., :cout].float().abs() + 1.0)).max()) <= 2.02 * ulp, it      # + the ReLU-pattern bump
     fused = int((sync[16:].view(torch.int64) >> 32).abs().sum()) > 0
     if fused:
         assert dt != "f32" and float(a.float().abs().max()) == 0.0       # the pre-norm activation was never written
@@ -475,6 +475,69 @@ def test_conv_in_fwd_one_launch_matches_the_two_call_form(ops, dt, case):
     z = co.conv_raw(x.double().cpu(), w.double(), dil) + bias.double()
     ref = co.instance_norm(torch.relu(z))
     assert relerr(y[..., :cout], ref) < {"f32": 1e-4, "f16": 3e-3, "bf16": 2e-2}[dt]
+
+
+@pytest.mark.parametrize("dt", ["f16", "bf16"])
+@pytest.mark.parametrize("case", CONV_IN_FWD_CASES[:5])
+def test_backward_from_y_alone(ops, dt, case):
+    """The layer gradient from the one-launch forward's output ALONE (CUTIE_ACT_FROM_Y: xhat = y, the ReLU pattern read
+    out of y's bits) against the same gradient from the stored pre-norm activation: the pattern element for element
+    (up to f32 activations that underflow in 16 bits), dz within the 16-bit tolerance and against float64; the
+    one-launch backward and the two-call backward agree bit for bit on the same operands."""
+    B, H, W, cin, cout, kh, kw, dil = case
+    g = torch.Generator().manual_seed(hash(case) % 1000 + 23)
+    tdt = TDT[dt]
+    w = (torch.randn((kh, kw, cin, cout), generator=g) * 0.05).to(tdt).float()
+    bias = torch.randn(cout, generator=g) * 0.1
+    bias[0] = 12.0                                      # a channel its bias dominates: no zeros in its planes
+    bias[1] = -40.0                                     # and a dead one: every element is y0
+    wf, _ = ops.pack_weights(w.to(DEV), CDT[dt], want_dgrad=False)
+    if wf.shape[2] != cin:
+        pytest.skip("padded cin")
+    cz = 64
+    w2 = (torch.randn((3, 5, cout, cz), generator=g) * 0.05).to(tdt).float()
+    _, wd = ops.pack_weights(w2.to(DEV), CDT[dt], want_fwd=False)
+    T = ops.conv_stats_tiles(H, W)
+    bd = bias.to(DEV)
+    x = _rand_act(g, (B, H, W, cin), tdt).to(DEV)
+    seg = [dict(x=x, w=wf, cin=cin, kh=kh, kw=kw, dil=dil)]
+    a = torch.zeros((B, H, W, cout), dtype=tdt, device=DEV)
+    y2 = torch.zeros((B, H, W, cout), dtype=tdt, device=DEV)
+    st2 = torch.zeros((B, T, cout, 2), dtype=torch.float32, device=DEV)
+    assert not ops.conv_in_fwd(seg, a, y2, cout, bd, True, st2, sync=None)
+    y = torch.zeros((B, H, W, cout), dtype=tdt, device=DEV)
+    st = torch.zeros((B, T, cout, 2), dtype=torch.float32, device=DEV)
+    sync_fw = torch.zeros(ops.conv_sync_bytes(B, T, cout) // 4, dtype=torch.int32, device=DEV)
+    if not ops.conv_in_fwd(seg, torch.zeros_like(a), y, cout, bd, True, st, sync=sync_fw):
+        pytest.skip("the entry point took the two-call form")
+    dzin = _rand_act(g, (B, H, W, cz), tdt).to(DEV)
+    bseg = [dict(x=dzin, w=wd, cin=wd.shape[2], kh=3, kw=5, dil=1, flip=True)]
+    out = {}
+    for key, av, from_y, use_sync in (("a", a, False, True), ("y", y, True, True), ("y2", y, True, False)):
+        dy = torch.zeros((B, H, W, cout), dtype=tdt, device=DEV)
+        dz = torch.zeros((B, H, W, cout), dtype=tdt, device=DEV)
+        red = torch.zeros((B, T, cout, 2), dtype=torch.float32, device=DEV)
+        dbp = torch.zeros((B * T, cout), dtype=torch.float32, device=DEV)
+        sync = torch.zeros(ops.conv_sync_bytes(B, T, cout) // 4, dtype=torch.int32, device=DEV) if use_sync else None
+        ops.conv_dgrad_in_bwd(bseg, dy, cout, av, st, red, dz, dbias_part=dbp, relu=True, sync=sync, bias=bd, from_y=from_y)
+        torch.cuda.synchronize()
+        assert sync is None or int(sync[0]) == 0
+        out[key] = (dz, dbp.view(B, T, cout).sum(dim=1))
+    assert torch.equal(out["y"][0], out["y2"][0])                         # one launch == two calls, from y
+    active = a > 0
+    got = out["y"][0] != 0
+    wrong = int((got & ~active).sum()), int((~got & active & (out["a"][0] != 0)).sum())
+    print("pattern read from y: %d set where a == 0, %d clear where a > 0, of %d" % (wrong + (active.numel(),)))
+    assert max(wrong) <= max(4, active.numel() // 1000000)
+    assert bool(active[..., 0].all()) and not bool(active[..., 1].any())
+    assert not bool(got[..., 1].any())
+    tol = {"f16": 2e-3, "bf16": 1.2e-2}[dt]
+    # (channel 0 aside: there the stored 16-bit activation is the coarse operand, y the fine one)
+    # and the few elements aside whose f32 activation is positive but underflows in 16 bits: y knows they are active
+    same = (got == (out["a"][0] != 0))
+    assert relerr((out["y"][0] * same)[..., 2:], (out["a"][0] * same)[..., 2:]) < tol
+    scale = out["a"][0].float().abs().sum(dim=(1, 2))
+    assert float(((out["y"][1] - out["a"][1]).abs() / (scale + 1e-20))[:, 2:].max()) < tol
 
 
 DGRAD_BWD_CASES = [

@@ -122,7 +122,7 @@ def test_cutie_aspp_forward_backward_parity(oracle_run, dtype):
     eng.loss_backward(P)
     ml, rg, tl = eng.losses(P)
     conv_names = [n.name for n in net.nodes if n.op == "conv"]
-    masks = {k: (P.a[k][..., :net.layers[k].channels] > 0).double().cpu() for k in conv_names}
+    masks = {k: eng.relu_mask(P, k).double().cpu() for k in conv_names}
     flips = sum(int(((L[k] - L[k].amin(dim=(1, 2), keepdim=True)).abs() < 1e-12).ne(masks[k] == 0).sum())
                 for k in conv_names)
     total = sum(masks[k].numel() for k in conv_names)
@@ -329,7 +329,7 @@ def test_cutie2_backward_parity(variant, B, H, W, Hi, dtype):
     torch.cuda.synchronize()
     S = eng.loss_scale_value()[0]
     conv_names = [n.name for n in net.nodes if n.op == "conv"]
-    masks = {k: (P.a[k][..., :net.layers[k].channels] > 0).double().cpu() for k in conv_names}
+    masks = {k: eng.relu_mask(P, k).double().cpu() for k in conv_names}
     o = c2.loss_and_grads(graph, params, grid, image.double(), ps, labels, masks=masks,
                           cell_weights=P.weight.double().cpu())
     ml, rg, tl = eng.losses(P)
@@ -386,7 +386,7 @@ def test_cutie_aspp_ghm_loss_and_gradients(oracle_run):
     print("GHM weights: share of elements in another bin than the f64 oracle's logits put them: %.2e" % differ)
     assert differ < 5e-3 and abs(float(w_dev.mean() / w_ref.mean()) - 1) < 1e-2
     conv_names = [n.name for n in net.nodes if n.op == "conv"]
-    masks = {k: (P.a[k][..., :net.layers[k].channels] > 0).double().cpu() for k in conv_names}
+    masks = {k: eng.relu_mask(P, k).double().cpu() for k in conv_names}
     o = co.loss_and_grads(r["params"], r["grid"], r["labels"], masks=masks, cell_weights=P.weight.double().cpu(),
                           activation="sigmoid", ghm_weights=w_dev)
     ml, rg, tl = eng.losses(P)
