@@ -18,7 +18,6 @@ struct Config {
     bool conv_lpt;        // CUTIE_CONV_LPT=0: conv_wide tiles in row-major order
     bool rendezvous;      // CUTIE_RENDEZVOUS=0: cutie_conv_dgrad_in_bwd always as data gradient + cutie_in_bwd_apply
     bool rv_nowait;       // CUTIE_RV_NOWAIT=1: diagnostic only, invalid results
-    bool conv_stagger;    // CUTIE_CONV_STAGGER=1 (default 0: measured 0.4 % slower): conv_wide waves 4-7 half a K step behind waves 0-3
 };
 const Config& config();
 

@@ -864,7 +864,7 @@ static int conv_fwd_impl(const cutie_conv_seg* segs, int n_segs, int B, int H, i
         q.n_tiles_n = (int)cutie::cdiv(n_out, bn);
         if ((long long)B * q.tiles_h * q.tiles_w * q.n_tiles_n < (1ll << 31)) {
             const bool fuse_on = cutie::config().fuse_norm_bwd;
-            const bool fuse = nb && fuse_on && nb->a_dtype == dtype && (nb->ld_a * 2) % 16 == 0 && cutie::aligned16(nb->a) &&
+            const bool fuse = nb && fuse_on && !bias && !relu && !stats && nb->a_dtype == dtype && (nb->ld_a * 2) % 16 == 0 && cutie::aligned16(nb->a) &&
                               q.tiles_h * q.tiles_w <= nb->red_tiles;
             bool meet = false;
             if (fuse) {

@@ -110,11 +110,30 @@ __device__ __forceinline__ void granule_sweep(const unsigned long long* slots, i
     if (late && (threadIdx.x & 63) == 0) atomicAdd(err, 1);
 }
 
+// element offset of (pixel row, channel) in the staged output tile: [256][BN] with the 16-byte chunk index XORed by the
+// row, so that the sixteen lanes of an 8-byte store group (sixteen rows, one chunk) land on different banks
+template <int BN>
+__device__ __forceinline__ int cs_off(int row, int ch) {
+    constexpr int PPR = BN / 8;
+    return row * BN + ((((ch >> 3) ^ (row & (PPR < 16 ? PPR - 1 : 15))) << 3) | (ch & 7));
+}
+// sum over the 16 lanes of a DPP row (all of them end up with it): xor 1, xor 2, half-row mirror, row mirror
+__device__ __forceinline__ float row16_sum(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));
+    return v;
+}
+
 // bias, ReLU, instance-norm moments, LDS-staged coalesced store of a 256-pixel x BN-channel tile.
 // With p.bw_a (data gradient of an instance-normalised layer) the store pass also takes this tile's share of
 // (sum dy, sum dy * xhat) from the ROUNDED dy it stores and the layer's forward activation, so that
 // cutie_in_bwd_apply can follow without a separate reduction pass over dy and a.
-template <int DT, int BN>
+// MODE: 0 plain (forward conv / plain data gradient), 1 data gradient + the norm gradient's two sums, 2 the same with the
+// sample's tiles meeting (dz out), 3 forward with the tiles meeting (y out).  A compile-time mode so that each path
+// allocates registers for itself (the backward modes hold 64 registers of forward activation across the staging).
+template <int DT, int BN, int MODE>
 __device__ __forceinline__ void conv_wide_epilogue(const ConvParams& p, float4_t (&acc)[Shape<BN>::MB][4], char* smem, int b,
                                                    int tile, int h0, int w0, int n0) {
     typedef Shape<BN> S;
@@ -129,19 +148,31 @@ __device__ __forceinline__ void conv_wide_epilogue(const ConvParams& p, float4_t
     constexpr int RG = CW_NT / PPR;      // pixel rows side by side in the store pass: 16 / 32 / 64
     constexpr int IT = 256 / RG;         // store iterations per lane: 16 / 8 / 4
     const int pc = tid % PPR, rg = tid / PPR;
-    const bool bw = p.bw_a != nullptr;
-    const bool rv = bw && p.rv_slots != nullptr;
+    constexpr bool bw = MODE == 1 || MODE == 2;
+    constexpr bool rv = MODE == 2;
     unsigned rv_tag = 0;
     if (rv) rv_tag = granule_tag(p.rv_slots, b, p.bw_red_tiles, tile, n_out, n0);
-    const bool fw = !bw && p.fw_slots != nullptr && p.stats != nullptr;     // forward: the tiles meet, y is stored, a is not
+    constexpr bool fw = MODE == 3;                                           // forward: the tiles meet, y is stored, a is not
+#ifdef CW_DIAG_NOEPI      // diagnostic build (tools/build_variant.sh): the K loop alone, results discarded
+    {
+        float s = 0.f;
+#pragma unroll
+        for (int m = 0; m < S::MB; ++m)
+#pragma unroll
+            for (int n = 0; n < 4; ++n) s += acc[m][n][0] + acc[m][n][1] + acc[m][n][2] + acc[m][n][3];
+        if (s == 1.2345e-33f) reinterpret_cast<float*>(p.out)[0] = s;
+        return;
+    }
+#endif
     unsigned fw_tag = 0;
     if (fw) fw_tag = granule_tag(p.fw_slots, b, p.stats_tiles, tile, n_out, n0);
 
     // the forward activation pieces and the forward moments are requested first: their latency passes
-    // under the staging of the accumulators
+    // under the staging of the accumulators (mode 2 holds the tile's dy in registers as well and has no room for them
+    // beside the accumulators: there they are requested right after the staging stores)
     uint4 av[IT];
     float fs = 0.f, fss = 0.f;
-    if (bw) {
+    auto load_av = [&]() {
 #pragma unroll
         for (int k = 0; k < IT; ++k) {
             const int ml = rg + k * RG;
@@ -152,6 +183,9 @@ __device__ __forceinline__ void conv_wide_epilogue(const ConvParams& p, float4_t
                 av[k] = *reinterpret_cast<const uint4*>(reinterpret_cast<const TO*>(p.bw_a) +
                                                         ((long long)(b * H + h) * W + w) * p.bw_ld_a + n0 + pc * 8);
         }
+    };
+    if constexpr (bw) {
+        if constexpr (!rv) load_av();
         if (tid < BN && n0 + tid < n_out) {
             // the slots in slot order, exactly as norm.hip's fold takes them
 #pragma unroll 4
@@ -172,37 +206,61 @@ __device__ __forceinline__ void conv_wide_epilogue(const ConvParams& p, float4_t
         norm_mean_inv(fs, fss, inv_n, n0 + tid < n_out ? norm_shift(p.bw_bias, p.bw_act & 15, n0 + tid) : 0.f, p.bw_eps,
                       tab[tid], tab[BN + tid]);
     }
+    // The MFMAs run with the weight fragment as the row operand: lane (li, lg) of accumulator [m][n] holds pixel
+    // mb * 16 + li and the FOUR CONSECUTIVE channels n * 16 + lg * 4 + r.  So a lane rounds and packs them into one 8-byte
+    // LDS store (32 ds_write_b64 per lane where the pixel-row layout took 128 two-byte stores, four lanes to a bank);
+    // the staged image is [256 pixels][BN channels] with the 16-byte chunk index XORed by the pixel row (cs_chunk).
 #pragma unroll
     for (int n = 0; n < 4; ++n) {
-        const int cl = wn * 64 + n * 16 + li;
-        const int col = n0 + cl;
-        const float bv = (p.bias && col < n_out) ? p.bias[col] : 0.f;
-        const float sh = p.relu ? fmaxf(bv, 0.f) : bv;      // norm_shift(p.bias, p.relu, col): the moments' shift
-        float s1 = 0.f, s2 = 0.f;
+        const int cb = wn * 64 + n * 16 + lg * 4;
+        if constexpr (bw) {      // a data gradient: no bias, no activation, no moments of its own (checked by the launcher)
 #pragma unroll
-        for (int m = 0; m < S::MB; ++m) {
-            const int mb = wm * S::MB + m;
-            const int h = h0 + mb / TCB;
+            for (int m = 0; m < S::MB; ++m) {
+                const int mb = wm * S::MB + m;
+                TO o[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) store_from_f32(&o[r], acc[m][n][r]);
+                *reinterpret_cast<uint2*>(Cs + cs_off<BN>(mb * 16 + li, cb)) = *reinterpret_cast<const uint2*>(o);
+            }
+        } else {
+            float bv[4], s1[4], s2[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int w = w0 + (mb % TCB) * 16 + lg * 4 + r;
-                float v = acc[m][n][r] + bv;
-                if (p.relu) v = fmaxf(v, 0.f);
+                bv[r] = (p.bias && n0 + cb + r < n_out) ? p.bias[n0 + cb + r] : 0.f;
+                s1[r] = 0.f;
+                s2[r] = 0.f;
+            }
+#pragma unroll
+            for (int m = 0; m < S::MB; ++m) {
+                const int mb = wm * S::MB + m;
+                const int h = h0 + mb / TCB, w = w0 + (mb % TCB) * 16 + li;
                 const bool inside = h < H && w < W;
-                if (!inside) v = 0.f;
-                const float d = inside ? v - sh : 0.f;
-                s1 += d;
-                s2 += d * d;
-                if (fw) acc[m][n][r] = v;        // stays in registers until the sample's moments are known
-                else store_from_f32(Cs + (mb * 16 + lg * 4 + r) * BN + cl, v);
+                TO o[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float v = acc[m][n][r] + bv[r];
+                    if (p.relu) v = fmaxf(v, 0.f);
+                    v = inside ? v : 0.f;
+                    // the moments are kept about norm_shift(p.bias, p.relu, col)
+                    const float d = inside ? v - (p.relu ? fmaxf(bv[r], 0.f) : bv[r]) : 0.f;
+                    s1[r] += d;
+                    s2[r] += d * d;
+                    if constexpr (fw) acc[m][n][r] = v;        // stays in registers until the sample's moments are known
+                    else store_from_f32(&o[r], v);
+                }
+                if constexpr (!fw) *reinterpret_cast<uint2*>(Cs + cs_off<BN>(mb * 16 + li, cb)) = *reinterpret_cast<const uint2*>(o);
+            }
+            if (p.stats) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    s1[r] = row16_sum(s1[r]);
+                    s2[r] = row16_sum(s2[r]);
+                    if (li == 0) wsum[wm * BN + cb + r] = make_float2(s1[r], s2[r]);
+                }
             }
         }
-        if (p.stats) {
-            s1 += __shfl_xor(s1, 16, 64); s1 += __shfl_xor(s1, 32, 64);
-            s2 += __shfl_xor(s2, 16, 64); s2 += __shfl_xor(s2, 32, 64);
-            if (lg == 0) wsum[wm * BN + cl] = make_float2(s1, s2);
-        }
     }
+    if constexpr (rv) load_av();
     __syncthreads();
     if (p.stats && tid < BN && n0 + tid < n_out) {
         // the tile's moments: the waves' partials added in wave order, STORED into this tile's slot -
@@ -229,24 +287,32 @@ __device__ __forceinline__ void conv_wide_epilogue(const ConvParams& p, float4_t
         __syncthreads();
 #pragma unroll
         for (int n = 0; n < 4; ++n) {
-            const int cl = wn * 64 + n * 16 + li;
-            const float mean = tab[cl], inv = tab[BN + cl];
-            const unsigned short y0 = y0_bits<TO>(mean, inv);
+            const int cb = wn * 64 + n * 16 + lg * 4;
+            float mean[4], inv[4];
+            unsigned short y0[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                mean[r] = tab[cb + r];
+                inv[r] = tab[BN + cb + r];
+                y0[r] = y0_bits<TO>(mean[r], inv[r]);
+            }
 #pragma unroll
             for (int m = 0; m < S::MB; ++m) {
                 const int mb = wm * S::MB + m;
+                TO o[4];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {    // y = (a - mean) * inv from the UNROUNDED activation: one rounding
                     const float v = acc[m][n][r];
                     TO yh;
-                    store_from_f32(&yh, (v - mean) * inv);
+                    store_from_f32(&yh, (v - mean[r]) * inv[r]);
                     // the ReLU pattern travels inside y (common.h): an active element never holds y0's bits
                     if (p.relu) {
-                        if (!(v > 0.f)) yh = __builtin_bit_cast(TO, y0);
-                        else if (bits16(yh) == y0) yh = __builtin_bit_cast(TO, next_up16(y0));
+                        if (!(v > 0.f)) yh = __builtin_bit_cast(TO, y0[r]);
+                        else if (bits16(yh) == y0[r]) yh = __builtin_bit_cast(TO, next_up16(y0[r]));
                     }
-                    Cs[(mb * 16 + lg * 4 + r) * BN + cl] = yh;
+                    o[r] = yh;
                 }
+                *reinterpret_cast<uint2*>(Cs + cs_off<BN>(mb * 16 + li, cb)) = *reinterpret_cast<const uint2*>(o);
             }
         }
         __syncthreads();
@@ -272,11 +338,14 @@ __device__ __forceinline__ void conv_wide_epilogue(const ConvParams& p, float4_t
         const int mb = ml >> 4;
         const int h = h0 + mb / TCB, w = w0 + (mb % TCB) * 16 + (ml & 15);
         if (h < H && w < W && col < n_out) {
-            const uint4 gv = *reinterpret_cast<const uint4*>(Cs + ml * BN + pc * 8);
+            const uint4 gv = *reinterpret_cast<const uint4*>(Cs + cs_off<BN>(ml, pc * 8));
             if (rv) {
                 gvk[k] = gv;
             } else {
                 TO* dst = reinterpret_cast<TO*>(p.out) + ((long long)(b * H + h) * W + w) * p.ld_out + col;
+#ifdef CW_DIAG_NOSTORE    // diagnostic build: everything but the output store
+                if (gv.x == 0x12345678u)
+#endif
                 *reinterpret_cast<uint4*>(dst) = gv;
             }
             if (bw) {
@@ -374,7 +443,8 @@ __device__ __forceinline__ void conv_wide_epilogue(const ConvParams& p, float4_t
     }
 }
 
-template <int DT, int BN, bool STG>
+// MODE: the epilogue (conv_wide_epilogue) - one kernel instance per mode, so that each allocates registers for its own path
+template <int DT, int BN, int MODE>
 __global__ __launch_bounds__(CW_NT) void conv_wide_kernel(ConvParams p) {
     typedef Shape<BN> S;
     constexpr int MB = S::MB, NB = S::NB, NP = S::NP;
@@ -542,7 +612,7 @@ __global__ __launch_bounds__(CW_NT) void conv_wide_kernel(ConvParams p) {
                 }
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int n = 0; n < 4; ++n) mma_frag<DT>(af0[m], bf0[n], acc[m][n]);
+                for (int n = 0; n < 4; ++n) mma_frag<DT>(bf0[n], af0[m], acc[m][n]);
                 __builtin_amdgcn_sched_barrier(0);
             }
         };
@@ -554,7 +624,7 @@ __global__ __launch_bounds__(CW_NT) void conv_wide_kernel(ConvParams p) {
                 for (int q = 0; q < NP; ++q)
                     if ((q * MB) / (2 * NP) == m) prefetch(q);
 #pragma unroll
-                for (int n = 0; n < 4; ++n) mma_frag<DT>(af1[m], bf1[n], acc[m][n]);
+                for (int n = 0; n < 4; ++n) mma_frag<DT>(bf1[n], af1[m], acc[m][n]);
             }
         };
         auto compute = [&](int bsel, auto prefetch) {
@@ -621,13 +691,12 @@ __global__ __launch_bounds__(CW_NT) void conv_wide_kernel(ConvParams p) {
 #pragma unroll
         for (int m = 0; m < MB; ++m)
 #pragma unroll
-            for (int n = 0; n < 4; ++n) mma_frag<DT>(af1[m], bf1[n], acc[m][n]);
+            for (int n = 0; n < 4; ++n) mma_frag<DT>(bf1[n], af1[m], acc[m][n]);
     }
     };
-    if (STG && wave >= 4) run(std::true_type{});
-    else run(std::false_type{});
+    run(std::false_type{});      // (std::true_type: the staggered schedule of round 2, measured 0.4 % slower, never instantiated)
 
-    conv_wide_epilogue<DT, BN>(p, acc, smem, b, th * p.tiles_w + tw, h0, w0, n0);
+    conv_wide_epilogue<DT, BN, MODE>(p, acc, smem, b, th * p.tiles_w + tw, h0, w0, n0);
 }
 
 
@@ -648,18 +717,26 @@ int conv_wide_tile(const ConvParams& p) {
     return 0;
 }
 
-template <int DT, int BN>
-static int launch_one(const ConvParams& p, hipStream_t stream) {
+template <int DT, int BN, int MODE>
+static int launch_mode(const ConvParams& p, hipStream_t stream) {
     const long long grid = (long long)p.B * p.tiles_h * p.tiles_w * p.n_tiles_n;
-    if (config().conv_stagger) {
-        CUTIE_ENSURE_LDS((conv_wide_kernel<DT, BN, true>), Shape<BN>::LDS);
-        hipLaunchKernelGGL((conv_wide_kernel<DT, BN, true>), dim3((unsigned)grid), dim3(CW_NT), Shape<BN>::LDS, stream, p);
-    } else {
-        CUTIE_ENSURE_LDS((conv_wide_kernel<DT, BN, false>), Shape<BN>::LDS);
-        hipLaunchKernelGGL((conv_wide_kernel<DT, BN, false>), dim3((unsigned)grid), dim3(CW_NT), Shape<BN>::LDS, stream, p);
-    }
+    CUTIE_ENSURE_LDS((conv_wide_kernel<DT, BN, MODE>), Shape<BN>::LDS);
+    hipLaunchKernelGGL((conv_wide_kernel<DT, BN, MODE>), dim3((unsigned)grid), dim3(CW_NT), Shape<BN>::LDS, stream, p);
     CUTIE_CHECK_LAUNCH();
     return CUTIE_OK;
+}
+
+template <int DT, int BN>
+static int launch_one(const ConvParams& p, hipStream_t stream) {
+    if (p.bw_a != nullptr) {
+        if (p.bias || p.relu || p.stats) {
+            set_error("conv_wide: a data gradient with fused norm sums takes no bias, activation or moments of its own");
+            return CUTIE_E_ARG;
+        }
+        return p.rv_slots != nullptr ? launch_mode<DT, BN, 2>(p, stream) : launch_mode<DT, BN, 1>(p, stream);
+    }
+    if (p.fw_slots != nullptr && p.stats != nullptr) return launch_mode<DT, BN, 3>(p, stream);
+    return launch_mode<DT, BN, 0>(p, stream);
 }
 
 // K steps of every pixel tile (live taps x channel chunks); returns false when there are more tiles than CONV_MAX_PERM
