@@ -206,6 +206,7 @@ __device__ __forceinline__ void conv_wide_epilogue(const ConvParams& p, float4_t
         norm_mean_inv(fs, fss, inv_n, n0 + tid < n_out ? norm_shift(p.bw_bias, p.bw_act & 15, n0 + tid) : 0.f, p.bw_eps,
                       tab[tid], tab[BN + tid]);
     }
+    const bool full_tile = h0 + p.TH <= H && w0 + TCB * 16 <= W;
     // The MFMAs run with the weight fragment as the row operand: lane (li, lg) of accumulator [m][n] holds pixel
     // mb * 16 + li and the FOUR CONSECUTIVE channels n * 16 + lg * 4 + r.  So a lane rounds and packs them into one 8-byte
     // LDS store (32 ds_write_b64 per lane where the pixel-row layout took 128 two-byte stores, four lanes to a bank);
@@ -223,32 +224,48 @@ __device__ __forceinline__ void conv_wide_epilogue(const ConvParams& p, float4_t
                 *reinterpret_cast<uint2*>(Cs + cs_off<BN>(mb * 16 + li, cb)) = *reinterpret_cast<const uint2*>(o);
             }
         } else {
-            float bv[4], s1[4], s2[4];
+            float bv[4], sh[4], s1[4], s2[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 bv[r] = (p.bias && n0 + cb + r < n_out) ? p.bias[n0 + cb + r] : 0.f;
+                sh[r] = p.relu ? fmaxf(bv[r], 0.f) : bv[r];      // norm_shift(p.bias, p.relu, col): the moments are kept about it
                 s1[r] = 0.f;
                 s2[r] = 0.f;
             }
+            // a tile that lies wholly inside the image (uniform per workgroup) needs no per-pixel masking
+            auto stage = [&](auto ragged, auto relu) {
 #pragma unroll
-            for (int m = 0; m < S::MB; ++m) {
-                const int mb = wm * S::MB + m;
-                const int h = h0 + mb / TCB, w = w0 + (mb % TCB) * 16 + li;
-                const bool inside = h < H && w < W;
-                TO o[4];
+                for (int m = 0; m < S::MB; ++m) {
+                    const int mb = wm * S::MB + m;
+                    bool inside = true;
+                    if constexpr (decltype(ragged)::value) {
+                        const int h = h0 + mb / TCB, w = w0 + (mb % TCB) * 16 + li;
+                        inside = h < H && w < W;
+                    }
+                    TO o[4];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    float v = acc[m][n][r] + bv[r];
-                    if (p.relu) v = fmaxf(v, 0.f);
-                    v = inside ? v : 0.f;
-                    // the moments are kept about norm_shift(p.bias, p.relu, col)
-                    const float d = inside ? v - (p.relu ? fmaxf(bv[r], 0.f) : bv[r]) : 0.f;
-                    s1[r] += d;
-                    s2[r] += d * d;
-                    if constexpr (fw) acc[m][n][r] = v;        // stays in registers until the sample's moments are known
-                    else store_from_f32(&o[r], v);
+                    for (int r = 0; r < 4; ++r) {
+                        float v = acc[m][n][r] + bv[r];
+                        if constexpr (decltype(relu)::value) v = fmaxf(v, 0.f);
+                        float d = v - sh[r];
+                        if constexpr (decltype(ragged)::value) {
+                            v = inside ? v : 0.f;
+                            d = inside ? d : 0.f;
+                        }
+                        s1[r] += d;
+                        s2[r] = __builtin_fmaf(d, d, s2[r]);
+                        if constexpr (fw) acc[m][n][r] = v;        // stays in registers until the sample's moments are known
+                        else store_from_f32(&o[r], v);
+                    }
+                    if constexpr (!fw) *reinterpret_cast<uint2*>(Cs + cs_off<BN>(mb * 16 + li, cb)) = *reinterpret_cast<const uint2*>(o);
                 }
-                if constexpr (!fw) *reinterpret_cast<uint2*>(Cs + cs_off<BN>(mb * 16 + li, cb)) = *reinterpret_cast<const uint2*>(o);
+            };
+            if (full_tile) {
+                if (p.relu) stage(std::false_type{}, std::true_type{});
+                else stage(std::false_type{}, std::false_type{});
+            } else {
+                if (p.relu) stage(std::true_type{}, std::true_type{});
+                else stage(std::true_type{}, std::false_type{});
             }
             if (p.stats) {
 #pragma unroll
