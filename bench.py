@@ -125,11 +125,16 @@ def pmc_traffic(dtype):
     if prof.get("source_sha") != kernel_source_sha():
         return None, "%s was taken with other kernel sources (source_sha %s != %s): not reported" % (
             rel, prof.get("source_sha"), kernel_source_sha())
-    k = prof["kernels"].get("conv_wide_kernel<%d, 256>" % {"bf16": 1, "f16": 2}.get(dtype, -1))
-    if not k:
-        return None, "%s holds no conv_wide_kernel<%s, 256>" % (rel, dtype)
-    return k["hbm_bytes_per_launch"], ("%s: (2*FETCH_SIZE + WRITE_SIZE)*1024 per conv_wide_kernel<%s,256> launch (tools/gpu_pmc.sh); "
-                                       "algorithmic bytes 136 MB forward, 203 MB data gradient with the fused norm sums" % (rel, dtype))
+    # one kernel instance per epilogue mode (plain / norm sums / backward rendezvous / forward rendezvous): launch-weighted mean
+    code = {"bf16": 1, "f16": 2}.get(dtype, -1)
+    ks = [v for name, v in prof["kernels"].items() if name.startswith("conv_wide_kernel<%d, 256," % code)]
+    if not ks:
+        return None, "%s holds no conv_wide_kernel<%s, 256, *>" % (rel, dtype)
+    n = sum(k["launches"] for k in ks)
+    per_launch = sum(k["hbm_bytes_per_launch"] * k["launches"] for k in ks) / n
+    return per_launch, ("%s: (2*FETCH_SIZE + WRITE_SIZE)*1024 per conv_wide_kernel<%s,256,*> launch, mean over its four epilogue "
+                        "modes weighted by launches (tools/gpu_pmc.sh); algorithmic bytes 136 MB forward, 203 MB data gradient "
+                        "with the fused norm gradient" % (rel, dtype))
 
 
 def cpu_baseline(num_classes, V, E, H, W, packed_docs):
