@@ -133,7 +133,9 @@ __device__ __forceinline__ float row16_sum(float v) {
 // MODE: 0 plain (forward conv / plain data gradient), 1 data gradient + the norm gradient's two sums, 2 the same with the
 // sample's tiles meeting (dz out), 3 forward with the tiles meeting (y out).  A compile-time mode so that each path
 // allocates registers for itself (the backward modes hold 64 registers of forward activation across the staging).
-template <int DT, int BN, int MODE>
+// FY (backward modes): bw_a is the layer's normalised output y (CUTIE_ACT_FROM_Y) - xhat = y, ReLU pattern out of y's bits;
+// RELU (mode 2): the layer has a ReLU.  Compile-time, so that the per-element code holds one formula, not a select of two.
+template <int DT, int BN, int MODE, bool FY, bool RELU>
 __device__ __forceinline__ void conv_wide_epilogue(const ConvParams& p, float4_t (&acc)[Shape<BN>::MB][4], char* smem, int b,
                                                    int tile, int h0, int w0, int n0) {
     typedef Shape<BN> S;
@@ -336,7 +338,7 @@ __device__ __forceinline__ void conv_wide_epilogue(const ConvParams& p, float4_t
     }
     const int col = n0 + pc * 8;
     float mean8[8], inv8[8], g1[8], g2[8];
-    const bool from_y = bw && (p.bw_act & CUTIE_ACT_FROM_Y);      // bw_a is the layer's normalised output: xhat = y
+    constexpr bool from_y = bw && FY;
     unsigned short y0b[8];
     if (bw) {
 #pragma unroll
@@ -372,7 +374,7 @@ __device__ __forceinline__ void conv_wide_epilogue(const ConvParams& p, float4_t
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     g1[e] += g[e];
-                    g2[e] += g[e] * (from_y ? x[e] : (x[e] - mean8[e]) * inv8[e]);
+                    g2[e] = __builtin_fmaf(g[e], from_y ? x[e] : (x[e] - mean8[e]) * inv8[e], g2[e]);
                 }
             }
         }
@@ -433,8 +435,8 @@ __device__ __forceinline__ void conv_wide_epilogue(const ConvParams& p, float4_t
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {     // the arithmetic of in_bwd_apply_kernel, operation for operation
                     const float xh = from_y ? x[e] : (x[e] - mean8[e]) * inv8[e];
-                    float d = inv8[e] * (g[e] - m1[e] - xh * m2[e]);
-                    if (p.rv_relu == 1) {
+                    float d = inv8[e] * __builtin_fmaf(-xh, m2[e], g[e] - m1[e]);
+                    if constexpr (RELU) {
                         const bool active = from_y ? (u16_of(av[k], e) != y0b[e]) : (x[e] > 0.f);
                         if (!active) d = 0.f;
                     }
@@ -461,7 +463,7 @@ __device__ __forceinline__ void conv_wide_epilogue(const ConvParams& p, float4_t
 }
 
 // MODE: the epilogue (conv_wide_epilogue) - one kernel instance per mode, so that each allocates registers for its own path
-template <int DT, int BN, int MODE>
+template <int DT, int BN, int MODE, bool FY, bool RELU>
 __global__ __launch_bounds__(CW_NT) void conv_wide_kernel(ConvParams p) {
     typedef Shape<BN> S;
     constexpr int MB = S::MB, NB = S::NB, NP = S::NP;
@@ -713,7 +715,7 @@ __global__ __launch_bounds__(CW_NT) void conv_wide_kernel(ConvParams p) {
     };
     run(std::false_type{});      // (std::true_type: the staggered schedule of round 2, measured 0.4 % slower, never instantiated)
 
-    conv_wide_epilogue<DT, BN, MODE>(p, acc, smem, b, th * p.tiles_w + tw, h0, w0, n0);
+    conv_wide_epilogue<DT, BN, MODE, FY, RELU>(p, acc, smem, b, th * p.tiles_w + tw, h0, w0, n0);
 }
 
 
@@ -734,11 +736,11 @@ int conv_wide_tile(const ConvParams& p) {
     return 0;
 }
 
-template <int DT, int BN, int MODE>
+template <int DT, int BN, int MODE, bool FY = false, bool RELU = false>
 static int launch_mode(const ConvParams& p, hipStream_t stream) {
     const long long grid = (long long)p.B * p.tiles_h * p.tiles_w * p.n_tiles_n;
-    CUTIE_ENSURE_LDS((conv_wide_kernel<DT, BN, MODE>), Shape<BN>::LDS);
-    hipLaunchKernelGGL((conv_wide_kernel<DT, BN, MODE>), dim3((unsigned)grid), dim3(CW_NT), Shape<BN>::LDS, stream, p);
+    CUTIE_ENSURE_LDS((conv_wide_kernel<DT, BN, MODE, FY, RELU>), Shape<BN>::LDS);
+    hipLaunchKernelGGL((conv_wide_kernel<DT, BN, MODE, FY, RELU>), dim3((unsigned)grid), dim3(CW_NT), Shape<BN>::LDS, stream, p);
     CUTIE_CHECK_LAUNCH();
     return CUTIE_OK;
 }
@@ -750,7 +752,11 @@ static int launch_one(const ConvParams& p, hipStream_t stream) {
             set_error("conv_wide: a data gradient with fused norm sums takes no bias, activation or moments of its own");
             return CUTIE_E_ARG;
         }
-        return p.rv_slots != nullptr ? launch_mode<DT, BN, 2>(p, stream) : launch_mode<DT, BN, 1>(p, stream);
+        const bool fy = (p.bw_act & CUTIE_ACT_FROM_Y) != 0;
+        if (p.rv_slots == nullptr) return fy ? launch_mode<DT, BN, 1, true>(p, stream) : launch_mode<DT, BN, 1, false>(p, stream);
+        if (p.rv_relu == 1)
+            return fy ? launch_mode<DT, BN, 2, true, true>(p, stream) : launch_mode<DT, BN, 2, false, true>(p, stream);
+        return fy ? launch_mode<DT, BN, 2, true, false>(p, stream) : launch_mode<DT, BN, 2, false, false>(p, stream);
     }
     if (p.fw_slots != nullptr && p.stats != nullptr) return launch_mode<DT, BN, 3>(p, stream);
     return launch_mode<DT, BN, 0>(p, stream);

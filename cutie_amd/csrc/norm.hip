@@ -223,7 +223,7 @@ __global__ __launch_bounds__(256) void in_bwd_stats_kernel(const TD* __restrict_
 #pragma unroll
             for (int e = 0; e < VEC; ++e) {
                 s1[e] += g.v[e];
-                s2[e] += g.v[e] * (from_y ? x.v[e] : (x.v[e] - mean[e]) * inv[e]);
+                s2[e] = __builtin_fmaf(g.v[e], from_y ? x.v[e] : (x.v[e] - mean[e]) * inv[e], s2[e]);
             }
         }
     }
@@ -273,7 +273,7 @@ __global__ __launch_bounds__(256) void in_bwd_apply_kernel(const TD* __restrict_
 #pragma unroll
             for (int e = 0; e < VEC; ++e) {
                 const float xh = from_y ? x.v[e] : (x.v[e] - mean[e]) * inv[e];
-                float d = inv[e] * (g.v[e] - m1[e] - xh * m2[e]);
+                float d = inv[e] * __builtin_fmaf(-xh, m2[e], g.v[e] - m1[e]);      // conv_wide's meeting tiles: the same operations
                 if (relu == 1) {
                     bool active = x.v[e] > 0.f;
                     if (from_y) {
