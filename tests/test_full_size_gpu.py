@@ -142,3 +142,39 @@ def test_full_batch_16bit_step(batch, dtype):
     assert out2["total_loss"] == out["total_loss"]
     if out["global_norm"] < 9.9:      # below the clip norm the embedding gradient's atomics cannot reach the other updates
         assert torch.equal(eng.params_flat[:eng.n_dense], after[:eng.n_dense])
+
+
+def test_training_trajectory_one_launch_vs_two_call_vs_f32(batch):
+    """Twelve Adam steps on 8 documents of the bench batch from one start, three ways: f32 (conv, norm and their
+    gradients as separate exact passes), f16 with every layer in its two-call form, f16 as shipped (forward and data
+    gradient in one launch each, the backward pass reading y only).  The loss falls on all three and the 16-bit
+    trajectories stay on the f32 one - an error in the ReLU pattern carried inside y, or in a tile meeting, would
+    show as a drift within a few steps."""
+    from cutie_amd.train import Trainer
+    grid, labels = batch["g"]["grid"][:8], batch["g"]["labels"][:8].to(torch.int32).clamp(0, C - 1)
+    runs = {}
+    start = None
+    for key, dtype, fused in (("f32", "f32", False), ("f16 two-call", "f16", False), ("f16", "f16", True)):
+        net, eng = _engine(dtype)
+        if start is None:
+            start = eng.params_flat.clone()
+        eng.params_flat.copy_(start)
+        eng.repack()
+        eng.train_fwd_fused = fused
+        tr = Trainer(eng, learning_rate=1e-3, check_inputs=True)
+        losses = [tr.step({"grid_table": grid, "gt_classes": labels})["model_loss"] for _ in range(12)]
+        if dtype == "f16":
+            P = eng.forward(grid, labels=labels)
+            assert any(P.fused.values()) == fused
+            assert eng.loss_scale_value()[1] == 0                     # no step was skipped for an overflow
+        runs[key] = np.asarray(losses, dtype=np.float64)
+        del eng, tr
+        torch.cuda.empty_cache()
+    for key, l in runs.items():
+        print("%-13s model loss by step: %s" % (key, " ".join("%.4f" % v for v in l)))
+        assert np.all(np.isfinite(l)) and l[-1] < 0.8 * l[0], key
+    ref = runs["f32"]
+    for key in ("f16 two-call", "f16"):
+        rel = np.abs(runs[key] - ref) / ref
+        assert rel[0] < 5e-3 and rel.max() < 6e-2, (key, rel)
+    assert np.abs(runs["f16"] - runs["f16 two-call"]).max() / ref.max() < 6e-2

@@ -12,7 +12,7 @@ dil = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 iters = int(sys.argv[3]) if len(sys.argv) > 3 else 20
 cin = int(sys.argv[4]) if len(sys.argv) > 4 else 256
 cout = int(sys.argv[5]) if len(sys.argv) > 5 else 256
-B, H, W, kh, kw = 32, 64, 64, 3, 5
+B, H, W, kh, kw = int(os.environ.get("CB_B", 32)), 64, 64, 3, 5
 dev = "cuda:0"
 g = torch.Generator().manual_seed(0)
 x = (torch.randn((B, H, W, cin), generator=g)).to(torch.bfloat16).to(dev)
