@@ -811,7 +811,11 @@ bool conv_wide_rendezvous_ok(const ConvParams& p, int bn, int* plain_order) {
     wavg /= nt;
     const double rounds = (double)((long long)p.B * per_sample + 255) / 256.0;
     const double step_us = 1.9 * bn / 256.0;
-    const double cost_us = (rounds < 1.0 ? 1.0 : rounds) * (wmax - wavg) * step_us;
+    // every channel lane sweeps the granules of all nt tiles, sixteen tiles in flight at a time (~2 us a batch): the first
+    // batch is part of the protocol's measured cost below, the others are not (CUTIE2-dilate 256x128, 128 tiles a sample:
+    // 363 docs/s with the tiles meeting against 381 without, tools/cutie2_bench.py)
+    const double sweep_us = (rounds < 1.0 ? 1.0 : rounds) * ((nt + 15) / 16 - 1) * 2.0;
+    const double cost_us = (rounds < 1.0 ? 1.0 : rounds) * (wmax - wavg) * step_us + sweep_us;
     const double saved_us = 6.0 * p.B * p.H * p.W * p.n_out / 5e6;
     if (cost_us > 0.5 * saved_us) return false;      // the launch's own protocol takes the other half (tools/dgrad_bench.py)
     *plain_order = per_sample > 32 ? 1 : 0;
@@ -828,7 +832,7 @@ bool conv_wide_fw_rendezvous_ok(const ConvParams& p, int bn, int* plain_order) {
     if (!tile_weights(p, weight, wmin, wmax)) return false;
     const int nt = p.tiles_h * p.tiles_w;
     const int per_sample = nt * p.n_tiles_n;
-    if (per_sample > 128) return false;
+    if (per_sample > 128 || nt > 32) return false;      // more than two batches of granules to sweep cost more than the pass saves
     double wavg = 0.0;
     for (int t = 0; t < nt; ++t) wavg += weight[t];
     wavg /= nt;

@@ -420,7 +420,8 @@ CONV_IN_FWD_CASES = [
     (2, 7, 80, 64, 512, 3, 5, 2),        # two channel tiles of 256
     (8, 64, 64, 64, 256, 3, 5, 16),      # unbalanced tiles: the entry point takes the two-call form itself
     (2, 12, 64, 64, 36, 3, 5, 1),        # not a wide-kernel shape: two-call form
-    (1, 160, 128, 64, 128, 3, 5, 1),     # 80 tiles a sample: plain block order
+    (1, 160, 128, 64, 128, 3, 5, 1),     # 80 tiles a sample: more granules to sweep than the pass is worth - two-call form
+    (8, 64, 128, 64, 512, 3, 5, 1),      # 32 tiles x 2 channel tiles a sample: plain block order
 ]
 
 
@@ -471,7 +472,7 @@ def test_conv_in_fwd_one_launch_matches_the_two_call_form(ops, dt, case):
                         torch.zeros((1, T, cout, 2), dtype=torch.float32, device=DEV), sync=s1)
         assert torch.equal(y1[..., :cout], y[B - 1:, :, :, :cout])
     else:
-        assert dt == "f32" or dil == 16 or cout == 36
+        assert dt == "f32" or dil == 16 or cout == 36 or H * W > 32 * 256
     z = co.conv_raw(x.double().cpu(), w.double(), dil) + bias.double()
     ref = co.instance_norm(torch.relu(z))
     assert relerr(y[..., :cout], ref) < {"f32": 1e-4, "f16": 3e-3, "bf16": 2e-2}[dt]
@@ -551,7 +552,8 @@ DGRAD_BWD_CASES = [
     (8, 64, 64, 64, 256, 16, "relu"),    # unbalanced tiles (dilation 16) with a short K loop: either form
     (32, 64, 64, 256, 256, 16, "relu"),  # the same with the model's K loop: the entry point takes the two-call form itself
     (2, 12, 64, 64, 36, 1, "relu"),      # not a wide-kernel shape: two-call form
-    (1, 160, 128, 64, 128, 1, "relu"),   # 80 tiles x 1 channel tile a sample: plain block order
+    (1, 160, 128, 64, 128, 1, "relu"),   # 80 tiles a sample: the sweep costs more than the pass - two-call form
+    (8, 64, 128, 64, 512, 1, "relu"),    # 32 tiles x 2 channel tiles a sample: plain block order
 ]
 
 
@@ -602,7 +604,7 @@ def test_conv_dgrad_in_bwd_matches_the_two_call_form(ops, dt, case):
         assert bool(((tags == 5) | (tags == 0)).all()) and int((tags == 5).sum()) >= 2 * B * C
         assert dt != "f32" and float(dy.float().abs().max()) == 0.0      # and dy was never written
     else:
-        assert dt == "f32" or case[5] == 16 or case[4] == 36      # only those may take the two-call form
+        assert dt == "f32" or case[5] == 16 or case[4] == 36 or case[1] * case[2] > 32 * 256      # only those may take the two-call form
     # against float64 of the same rounded operands (last iteration)
     a64, d64 = ad[..., :C].double().cpu(), dy_ref[..., :C].double().cpu()
     mean = a64.mean(dim=(1, 2), keepdim=True)
