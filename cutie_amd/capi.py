@@ -35,6 +35,13 @@ class PackDesc(ctypes.Structure):
                 ("cin_pad", ctypes.c_int), ("cout_pad", ctypes.c_int)]
 
 
+class WgradDesc(ctypes.Structure):
+    _fields_ = [("x", ctypes.c_void_p), ("ld_x", ctypes.c_int), ("cin", ctypes.c_int),
+                ("dz", ctypes.c_void_p), ("ld_dz", ctypes.c_int), ("cout", ctypes.c_int),
+                ("B", ctypes.c_int), ("H", ctypes.c_int), ("W", ctypes.c_int), ("kh", ctypes.c_int), ("kw", ctypes.c_int),
+                ("dil", ctypes.c_int), ("dw", ctypes.c_void_p), ("accumulate", ctypes.c_int)]
+
+
 class SumRowsDesc(ctypes.Structure):
     _fields_ = [("part", ctypes.c_void_p), ("out", ctypes.c_void_p), ("C", ctypes.c_int)]
 
@@ -66,6 +73,8 @@ SIGNATURES = {
                                      _vp, _vp, _i, _vp, _i, _vp, _sz, _i, _vp]),
     "cutie_conv_wgrad_workspace_bytes": (_sz, [_i, _i, _i, _i, _i, _i, _i]),
     "cutie_conv_wgrad": (_i, [_vp, _i, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _i, _i, _vp, _sz, _vp]),
+    "cutie_conv_wgrad_batched_workspace_bytes": (_sz, [_c.POINTER(WgradDesc), _i, _i]),
+    "cutie_conv_wgrad_batched": (_i, [_c.POINTER(WgradDesc), _i, _i, _vp, _sz, _vp]),
     "cutie_pack_weights": (_i, [_vp, _i, _i, _i, _vp, _i, _vp, _i, _i, _vp]),
     "cutie_pack_weights_batched": (_i, [_c.POINTER(PackDesc), _i, _i, _vp]),
     "cutie_in_tiles": (_i, [_i, _i, _i]),

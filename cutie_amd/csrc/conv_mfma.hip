@@ -468,8 +468,18 @@ struct Wgrad5Params {
 //   16 cin x 64 cout - so that no wave multiplies the padding half of a 128-wide cout tile.
 //   WIDEPATCH: a patch of up to 128 rows (64 + 2 x 32 halo: dilation 16 on an image wider than one 64-pixel
 //   segment) - a fourth x piece per wave fills the 32 KB a patch buffer has.
-template <int DT, int KW, int MASK, bool NARROW = false, bool WIDEPATCH = false>
-__global__ __launch_bounds__(WG5_NT, 2) void wgrad5_kernel(Wgrad5Params p) {
+// several layers in ONE launch (cutie_conv_wgrad_batched): workgroups [start[i], start[i+1]) belong to layer i.  With
+// G = sum of the layers' (tap row, cin tile, cout tile) groups in one launch, 256 CUs are filled by 256 / G K splits
+// instead of 256 / 12: a third of the slab bytes, of the reduction reads and of the per-workgroup prologues.
+constexpr int WG5_MAXB = 16;
+struct Wgrad5Batch {
+    Wgrad5Params p[WG5_MAXB];
+    int pair_start[WG5_MAXB + 1];   // (layer, K split) pairs are numbered layer by layer: layer i owns [pair_start[i], pair_start[i+1])
+    int n, gmax;                    // gmax = the most (tap row, cin tile, cout tile) groups any layer of the launch has
+};
+
+template <int DT, int KW, int MASK, bool NARROW, bool WIDEPATCH>
+__device__ __forceinline__ void wgrad5_body(const Wgrad5Params& p, const int split, int bid) {
     constexpr int ES = 2;
     constexpr int MBLK = NARROW ? 1 : 2;     // 16-channel cin blocks per wave
     constexpr int ROWB = 256;       // bytes per staged pixel row: 128 channels
@@ -487,17 +497,6 @@ __global__ __launch_bounds__(WG5_NT, 2) void wgrad5_kernel(Wgrad5Params p) {
     const int li = lane & 15, lg = lane >> 4;
     const int H = p.H, W = p.W, dil = p.dil, pad = p.pad;
 
-    // Workgroups that multiply the SAME pixels (one K split; different tap row / channel tiles)
-    // should meet in one L2: hardware deals consecutive ids round-robin over the 8 XCDs, so give
-    // each XCD a contiguous run of logical ids (bijective for any grid size) and make the K split
-    // the slow index of the logical id.
-    const int groups = p.kh * p.mt * p.ntile;
-    const int nwg = groups * p.splits;
-    const int hw_id = blockIdx.x;
-    const int qx = nwg >> 3, rx = nwg & 7, xcd = hw_id & 7;
-    const int logical = (xcd < rx ? xcd * (qx + 1) : rx * (qx + 1) + (xcd - rx) * qx) + (hw_id >> 3);
-    const int split = logical / groups;
-    int bid = logical - split * groups;
     const int nt = bid % p.ntile; bid /= p.ntile;
     const int mt = bid % p.mt;
     const int ti = bid / p.mt;                 // tap row
@@ -671,15 +670,73 @@ __global__ __launch_bounds__(WG5_NT, 2) void wgrad5_kernel(Wgrad5Params p) {
     }
 }
 
+template <int DT, int KW, int MASK, bool NARROW = false, bool WIDEPATCH = false>
+__global__ __launch_bounds__(WG5_NT, 2) void wgrad5_kernel(Wgrad5Params p) {
+    // Workgroups that multiply the SAME pixels (one K split; different tap row / channel tiles)
+    // should meet in one L2: hardware deals consecutive ids round-robin over the 8 XCDs, so give
+    // each XCD a contiguous run of logical ids (bijective for any grid size) and make the K split
+    // the slow index of the logical id.
+    const int groups = p.kh * p.mt * p.ntile;
+    const int nwg = groups * p.splits;
+    const int hw_id = blockIdx.x;
+    const int qx = nwg >> 3, rx = nwg & 7, xcd = hw_id & 7;
+    const int logical = (xcd < rx ? xcd * (qx + 1) : rx * (qx + 1) + (xcd - rx) * qx) + (hw_id >> 3);
+    const int split = logical / groups;
+    wgrad5_body<DT, KW, MASK, NARROW, WIDEPATCH>(p, split, logical - split * groups);
+}
+
+template <int DT, int KW, int MASK, bool NARROW = false, bool WIDEPATCH = false>
+__global__ __launch_bounds__(WG5_NT, 2) void wgrad5_batched_kernel(Wgrad5Batch bt) {
+    // XCD x (= blockIdx & 7) takes the pairs x, x + 8, ...; the gmax consecutive workgroups it is dealt belong to ONE pair,
+    // so that the workgroups that read the same pixels run side by side behind one L2
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    const int pair = (j / bt.gmax) * 8 + xcd, group = j % bt.gmax;
+    if (pair >= bt.pair_start[bt.n]) return;       // (uniform)
+    int i = 0;
+#pragma unroll
+    for (int k = 1; k < WG5_MAXB; ++k)
+        if (k < bt.n && pair >= bt.pair_start[k]) i = k;
+    const Wgrad5Params p = bt.p[i];
+    if (group >= p.kh * p.mt * p.ntile) return;    // a layer with fewer groups than gmax
+    wgrad5_body<DT, KW, MASK, NARROW, WIDEPATCH>(p, pair - bt.pair_start[i], group);
+}
+
+// slabs -> gradient for several layers in one launch: blocks [start[i], start[i+1]) walk layer i
+struct ReduceBatch {
+    const float* slabs[WG5_MAXB];
+    float* dw[WG5_MAXB];
+    long long n[WG5_MAXB];
+    int splits[WG5_MAXB], accumulate[WG5_MAXB], start[WG5_MAXB + 1];
+    int cnt;
+};
+__device__ __forceinline__ void wgrad_reduce_body(const float* __restrict__ slabs, int splits, long long n, float* __restrict__ dw,
+                                                  int accumulate, long long first, long long stride);
+
+__global__ __launch_bounds__(256) void wgrad_reduce_batched_kernel(ReduceBatch rb) {
+    int i = 0;
+#pragma unroll
+    for (int j = 1; j < WG5_MAXB; ++j)
+        if (j < rb.cnt && (int)blockIdx.x >= rb.start[j]) i = j;
+    const int nb = rb.start[i + 1] - rb.start[i];
+    wgrad_reduce_body(rb.slabs[i], rb.splits[i], rb.n[i], rb.dw[i], rb.accumulate[i],
+                      (long long)((int)blockIdx.x - rb.start[i]) * blockDim.x + threadIdx.x, (long long)nb * blockDim.x);
+}
+
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slabs, int splits, long long n,
                                                            float* __restrict__ dw, int accumulate) {
+    wgrad_reduce_body(slabs, splits, n, dw, accumulate, (long long)blockIdx.x * blockDim.x + threadIdx.x,
+                      (long long)gridDim.x * blockDim.x);
+}
+
+__device__ __forceinline__ void wgrad_reduce_body(const float* __restrict__ slabs, int splits, long long n, float* __restrict__ dw,
+                                                  int accumulate, long long first, long long stride) {
     // n is a multiple of 4 whenever cout is (every layer but the 18-class logits): 16-byte lanes, four
     // slabs in flight per lane; the summation order over the slabs is fixed either way
     if ((n & 3) == 0 && ((reinterpret_cast<uintptr_t>(slabs) | reinterpret_cast<uintptr_t>(dw)) & 15) == 0) {
         const long long n4 = n >> 2;
         const float4* __restrict__ s4 = reinterpret_cast<const float4*>(slabs);
         float4* __restrict__ d4 = reinterpret_cast<float4*>(dw);
-        for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+        for (long long i = first; i < n4; i += stride) {
             float4 s = accumulate ? d4[i] : make_float4(0.f, 0.f, 0.f, 0.f);
             int k = 0;
             for (; k + 4 <= splits; k += 4) {
@@ -698,7 +755,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
         }
         return;
     }
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    for (long long i = first; i < n; i += stride) {
         float s = accumulate ? dw[i] : 0.f;
         for (int k = 0; k < splits; ++k) s += slabs[(long long)k * n + i];
         dw[i] = s;
@@ -1000,6 +1057,130 @@ extern "C" int cutie_conv_dgrad_in_bwd(const cutie_conv_seg* segs, int n_segs, i
                               dtype, dbias_part, dbias_tiles, B, H * W, n_out, shift_bias, stream_);
 }
 
+namespace {
+// which wgrad5 instance a layer runs on (canonical: the template arguments of the kernel)
+struct Wg5Key {
+    int kw, mask, narrow, wide;
+    bool operator==(const Wg5Key& o) const { return kw == o.kw && mask == o.mask && narrow == o.narrow && wide == o.wide; }
+};
+
+// fills q (all but slabs / splits) and key; false when the layer is not a wgrad5 shape (f32, kw > 5, 2 GB views)
+bool plan_wgrad5(const void* x, int ld_x, int cin, const void* dz, int ld_dz, int cout, int B, int H, int W, int kh, int kw,
+                 int dil, int dtype, Wgrad5Params& q, Wg5Key& key) {
+    const int es = 2;
+    if (dtype == CUTIE_F32 || kw > WG5_KW || !(kw == 1 || kw == 3 || kw == 5)) return false;
+    if ((long long)B * H * W * (ld_x > ld_dz ? ld_x : ld_dz) * es >= (1ll << 31)) return false;
+    q.x = (const char*)x; q.dz = (const char*)dz; q.ld_x = ld_x; q.cin = cin; q.ld_dz = ld_dz; q.cout = cout;
+    q.B = B; q.H = H; q.W = W; q.kh = kh; q.kw = kw; q.dil = dil;
+    q.slabs = nullptr; q.splits = 1;
+    q.mt = (int)cutie::cdiv(cin, kw == 1 ? 256 : 128);
+    q.ntile = (int)cutie::cdiv(cout, 128);
+    q.nwseg = (int)cutie::cdiv(W, WG5_PIX);
+    // halo columns: with one 64-pixel segment per row everything beyond the image is zero
+    // padding and a live 32-pixel K block reaches at most |shift| mod 32 columns outside
+    int pad = 0;
+    for (int t = 0; t < kw; ++t) {
+        int sx = (t - kw / 2) * dil;
+        if (sx < 0) sx = -sx;
+        const int need = q.nwseg == 1 ? sx % 32 : sx;
+        if (need > pad) pad = need;
+    }
+    q.pad = pad;
+    const int pwx = WG5_PIX + 2 * pad;
+    const bool widepatch = pwx > WG5_XROWS;
+    if (!(pwx <= WG5_XROWS || (pwx <= WG5_XROWS_WIDE && kw == 5 && cout > 64))) return false;
+    // liveness pattern of the (K block, tap) pairs when a row is one 64-pixel segment
+    int mask = -1;
+    if (q.nwseg == 1 && kw == 5 && W > 32) {
+        mask = 0;
+        for (int ks = 0; ks < 2; ++ks)
+            for (int t = 0; t < kw; ++t) {
+                const int px0 = ks * 32, sx = (t - kw / 2) * dil;
+                if (!(px0 + sx + 31 < 0 || px0 + sx >= W)) mask |= 1 << (ks * kw + t);
+            }
+    } else if (q.nwseg > 1 && kw == 5 && 2 * dil <= 31) {
+        // several segments per row, every shift shorter than a K block: no (K block, tap) pair is ever wholly
+        // outside on the left, and what lies beyond the right edge is staged as zeros - the all-live pattern
+        // (compile-time, so the row loop pipelines) is exact
+        mask = 0x3FF;
+    }
+    const bool narrow = cout <= 64;      // one cout tile, half of it (or more) padding
+    key.kw = kw; key.wide = widepatch ? 1 : 0; key.narrow = (!widepatch && narrow) ? 1 : 0;
+    if (widepatch) key.mask = -1;
+    else if (narrow) key.mask = (kw == 5 && mask == 0x3FF) ? 0x3FF : -1;
+    else key.mask = (kw == 5 && (mask == 0x3FF || mask == 0x1FE)) ? mask : -1;
+    return true;
+}
+
+// calls f with the instance's template arguments as integral constants
+template <typename F>
+void wg5_dispatch(int dtype, const Wg5Key& k, F&& f) {
+    using std::integral_constant;
+    using std::bool_constant;
+    auto with_dt = [&](auto kwc, auto maskc, auto narrowc, auto widec) {
+        if (dtype == CUTIE_BF16) f(integral_constant<int, CUTIE_BF16>{}, kwc, maskc, narrowc, widec);
+        else f(integral_constant<int, CUTIE_F16>{}, kwc, maskc, narrowc, widec);
+    };
+    typedef integral_constant<int, 5> K5;
+    typedef integral_constant<int, 3> K3;
+    typedef integral_constant<int, 1> K1;
+    typedef integral_constant<int, -1> MG;
+    typedef integral_constant<int, 0x3FF> MA;
+    typedef integral_constant<int, 0x1FE> MD;
+    typedef bool_constant<true> T;
+    typedef bool_constant<false> N;
+    if (k.wide) with_dt(K5{}, MG{}, N{}, T{});
+    else if (k.narrow) {
+        if (k.kw == 5 && k.mask == 0x3FF) with_dt(K5{}, MA{}, T{}, N{});
+        else if (k.kw == 5) with_dt(K5{}, MG{}, T{}, N{});
+        else if (k.kw == 3) with_dt(K3{}, MG{}, T{}, N{});
+        else with_dt(K1{}, MG{}, T{}, N{});
+    } else if (k.kw == 5 && k.mask == 0x3FF) with_dt(K5{}, MA{}, N{}, N{});
+    else if (k.kw == 5 && k.mask == 0x1FE) with_dt(K5{}, MD{}, N{}, N{});
+    else if (k.kw == 5) with_dt(K5{}, MG{}, N{}, N{});
+    else if (k.kw == 3) with_dt(K3{}, MG{}, N{}, N{});
+    else with_dt(K1{}, MG{}, N{}, N{});
+}
+
+// K splits for a batched launch: the same units per workgroup for every layer of the launch (s for the layer with the
+// most units, proportionally fewer for the others); s minimises a time model - rounds of 256 workgroups x (rows per
+// workgroup x 1.65 us + 8 us of prologue and slab store) + the slab bytes written and read back at 5 TB/s (constants
+// from the single-layer kernel on the MI355X: 97 rows a workgroup in 160 us, tools/conv_bench.py)
+int batched_splits(const Wgrad5Params* q, int n, int* splits) {
+    long long umax = 1;
+    int gmax = 1;
+    for (int i = 0; i < n; ++i) {
+        const long long u = (long long)q[i].B * q[i].H * q[i].nwseg;
+        if (u > umax) umax = u;
+        const int g = q[i].kh * q[i].mt * q[i].ntile;
+        if (g > gmax) gmax = g;
+    }
+    auto split_of = [&](int i, int s) {
+        const long long u = (long long)q[i].B * q[i].H * q[i].nwseg;
+        long long si = (s * u + umax / 2) / umax;
+        if (si > u) si = u;
+        return (int)(si < 1 ? 1 : si);
+    };
+    double best = 1e30;
+    int best_s = 1;
+    for (int s = 1; s <= 256 && s <= umax; ++s) {
+        long long pairs = 0;
+        double slab_bytes = 0.0;
+        for (int i = 0; i < n; ++i) {
+            const int si = split_of(i, s);
+            pairs += si;
+            slab_bytes += (double)si * q[i].kh * q[i].kw * q[i].cin * q[i].cout * 4.0;
+        }
+        const long long wgs = ((pairs + 7) / 8) * 8 * gmax;       // what the launch dispatches (idle ones included)
+        const long long rounds = (wgs + 255) / 256;
+        const double t = rounds * ((double)umax / s * 1.65 + 8.0) + 2.0 * slab_bytes / 5e6;
+        if (t < best) { best = t; best_s = s; }
+    }
+    for (int i = 0; i < n; ++i) splits[i] = split_of(i, best_s);
+    return gmax;
+}
+}  // namespace
+
 extern "C" size_t cutie_conv_wgrad_workspace_bytes(int B, int H, int W, int cin, int cout, int kh, int kw) {
     if (B < 1 || H < 1 || W < 1 || cin < 1 || cout < 1 || kh < 1 || kw < 1) return 0;
     int s = wgrad_splits(B, H, cin, cout, kh * kw);
@@ -1036,81 +1217,23 @@ extern "C" int cutie_conv_wgrad(const void* x, int ld_x, int cin, const void* dz
     const long long n_w = (long long)kh * kw * cin * cout;
     long long g_red = cutie::cdiv((n_w & 3) == 0 ? n_w / 4 : n_w, 256);
     if (g_red > 4096) g_red = 4096;
-    if (dtype != CUTIE_F32 && kw <= WG5_KW && (long long)B * H * W * (ld_x > ld_dz ? ld_x : ld_dz) * es < (1ll << 31)) {
-        Wgrad5Params q;
-        q.x = (const char*)x; q.dz = (const char*)dz; q.ld_x = ld_x; q.cin = cin; q.ld_dz = ld_dz; q.cout = cout;
-        q.B = B; q.H = H; q.W = W; q.kh = kh; q.kw = kw; q.dil = dil;
+    Wgrad5Params q;
+    Wg5Key key;
+    if (plan_wgrad5(x, ld_x, cin, dz, ld_dz, cout, B, H, W, kh, kw, dil, dtype, q, key)) {
         q.slabs = (float*)workspace;
         q.splits = wgrad5_splits(B, H, W, cin, cout, kh, kw);
-        q.mt = (int)cutie::cdiv(cin, kw == 1 ? 256 : 128);
-        q.ntile = (int)cutie::cdiv(cout, 128);
-        q.nwseg = (int)cutie::cdiv(W, WG5_PIX);
-        // halo columns: with one 64-pixel segment per row everything beyond the image is zero
-        // padding and a live 32-pixel K block reaches at most |shift| mod 32 columns outside
-        int pad = 0;
-        for (int t = 0; t < kw; ++t) {
-            int sx = (t - kw / 2) * dil;
-            if (sx < 0) sx = -sx;
-            const int need = q.nwseg == 1 ? sx % 32 : sx;
-            if (need > pad) pad = need;
-        }
-        q.pad = pad;
-        const int pwx = WG5_PIX + 2 * pad;
-        const bool widepatch = pwx > WG5_XROWS;
-        if ((pwx <= WG5_XROWS || (pwx <= WG5_XROWS_WIDE && kw == 5 && cout > 64)) && (kw == 1 || kw == 3 || kw == 5)) {
-            // liveness pattern of the (K block, tap) pairs when a row is one 64-pixel segment
-            int mask = -1;
-            if (q.nwseg == 1 && kw == 5 && W > 32) {
-                mask = 0;
-                for (int ks = 0; ks < 2; ++ks)
-                    for (int t = 0; t < kw; ++t) {
-                        const int px0 = ks * 32, sx = (t - kw / 2) * dil;
-                        if (!(px0 + sx + 31 < 0 || px0 + sx >= W)) mask |= 1 << (ks * kw + t);
-                    }
-            } else if (q.nwseg > 1 && kw == 5 && 2 * dil <= 31) {
-                // several segments per row, every shift shorter than a K block: no (K block, tap) pair is ever wholly
-                // outside on the left, and what lies beyond the right edge is staged as zeros - the all-live pattern
-                // (compile-time, so the row loop pipelines) is exact
-                mask = 0x3FF;
-            }
-            const dim3 grid5(kh * q.mt * q.ntile * q.splits);
-#define CUTIE_WG5_LAUNCH_DT(DT_, KW_, MASK_, NARROW_)                                                             \
-    do {                                                                                                          \
-        CUTIE_ENSURE_LDS((wgrad5_kernel<DT_, KW_, MASK_, NARROW_>), WG5_LDS);                                     \
-        hipLaunchKernelGGL((wgrad5_kernel<DT_, KW_, MASK_, NARROW_>), grid5, dim3(WG5_NT), WG5_LDS, stream, q);   \
-    } while (0)
-#define CUTIE_WG5_LAUNCH(KW_, MASK_, NARROW_)                                                                     \
-    do {                                                                                                          \
-        if (dtype == CUTIE_BF16) CUTIE_WG5_LAUNCH_DT(CUTIE_BF16, KW_, MASK_, NARROW_);                            \
-        else CUTIE_WG5_LAUNCH_DT(CUTIE_F16, KW_, MASK_, NARROW_);                                                 \
-    } while (0)
-            const bool narrow = cout <= 64;      // one cout tile, half of it (or more) padding
-            if (widepatch) {
-                if (dtype == CUTIE_BF16) {
-                    CUTIE_ENSURE_LDS((wgrad5_kernel<CUTIE_BF16, 5, -1, false, true>), WG5_LDS);
-                    hipLaunchKernelGGL((wgrad5_kernel<CUTIE_BF16, 5, -1, false, true>), grid5, dim3(WG5_NT), WG5_LDS, stream, q);
-                } else {
-                    CUTIE_ENSURE_LDS((wgrad5_kernel<CUTIE_F16, 5, -1, false, true>), WG5_LDS);
-                    hipLaunchKernelGGL((wgrad5_kernel<CUTIE_F16, 5, -1, false, true>), grid5, dim3(WG5_NT), WG5_LDS, stream, q);
-                }
-            } else if (narrow) {
-                if (kw == 5 && mask == 0x3FF) CUTIE_WG5_LAUNCH(5, 0x3FF, true);
-                else if (kw == 5) CUTIE_WG5_LAUNCH(5, -1, true);
-                else if (kw == 3) CUTIE_WG5_LAUNCH(3, -1, true);
-                else CUTIE_WG5_LAUNCH(1, -1, true);
-            } else if (kw == 5 && mask == 0x3FF) CUTIE_WG5_LAUNCH(5, 0x3FF, false);
-            else if (kw == 5 && mask == 0x1FE) CUTIE_WG5_LAUNCH(5, 0x1FE, false);
-            else if (kw == 5) CUTIE_WG5_LAUNCH(5, -1, false);
-            else if (kw == 3) CUTIE_WG5_LAUNCH(3, -1, false);
-            else CUTIE_WG5_LAUNCH(1, -1, false);
-#undef CUTIE_WG5_LAUNCH
-#undef CUTIE_WG5_LAUNCH_DT
-            CUTIE_CHECK_LAUNCH();
-            hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)g_red), dim3(256), 0, stream, (const float*)workspace,
-                               q.splits, n_w, dw, accumulate);
-            CUTIE_CHECK_LAUNCH();
-            return CUTIE_OK;
-        }
+        const dim3 grid5(kh * q.mt * q.ntile * q.splits);
+        wg5_dispatch(dtype, key, [&](auto dt, auto kwc, auto maskc, auto narrowc, auto widec) {
+            constexpr auto fn = wgrad5_kernel<decltype(dt)::value, decltype(kwc)::value, decltype(maskc)::value,
+                                              decltype(narrowc)::value, decltype(widec)::value>;
+            cutie::ensure_dyn_lds((const void*)fn, WG5_LDS);
+            hipLaunchKernelGGL(fn, grid5, dim3(WG5_NT), WG5_LDS, stream, q);
+        });
+        CUTIE_CHECK_LAUNCH();
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)g_red), dim3(256), 0, stream, (const float*)workspace,
+                           q.splits, n_w, dw, accumulate);
+        CUTIE_CHECK_LAUNCH();
+        return CUTIE_OK;
     }
     WgradParams p;
     p.x = (const char*)x; p.dz = (const char*)dz; p.ld_x = ld_x; p.cin = cin; p.ld_dz = ld_dz; p.cout = cout;
@@ -1135,5 +1258,152 @@ extern "C" int cutie_conv_wgrad(const void* x, int ld_x, int cin, const void* dz
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)g), dim3(256), 0, stream, (const float*)workspace, p.splits, n,
                        dw, accumulate);
     CUTIE_CHECK_LAUNCH();
+    return CUTIE_OK;
+}
+
+namespace {
+struct WgradPlan {      // how cutie_conv_wgrad_batched lays a call out: shared by the size query and the launch
+    int n5;                              // layers on the wgrad5 path
+    int idx[CUTIE_MAX_BATCH];            // their positions in descs, grouped by kernel instance
+    int group_of[CUTIE_MAX_BATCH];       // group number of idx[k]
+    Wgrad5Params q[CUTIE_MAX_BATCH];
+    Wg5Key key[CUTIE_MAX_BATCH];
+    size_t slab_off[CUTIE_MAX_BATCH];    // byte offset of the layer's slabs in the workspace
+    size_t bytes5;                       // workspace of the wgrad5 layers
+    size_t bytes_single;                 // largest workspace among the layers that take cutie_conv_wgrad by themselves
+};
+
+void plan_batched(const cutie_wgrad_desc* d, int n, int dtype, WgradPlan& pl) {
+    pl.n5 = 0; pl.bytes5 = 0; pl.bytes_single = 0;
+    Wgrad5Params q[CUTIE_MAX_BATCH];
+    Wg5Key key[CUTIE_MAX_BATCH];
+    bool ok[CUTIE_MAX_BATCH], taken[CUTIE_MAX_BATCH];
+    for (int i = 0; i < n; ++i) {
+        ok[i] = d[i].B > 0 && plan_wgrad5(d[i].x, d[i].ld_x, d[i].cin, d[i].dz, d[i].ld_dz, d[i].cout, d[i].B, d[i].H, d[i].W,
+                                          d[i].kh, d[i].kw, d[i].dil, dtype, q[i], key[i]);
+        taken[i] = false;
+        if (!ok[i] && d[i].B > 0) {
+            const size_t b = cutie_conv_wgrad_workspace_bytes(d[i].B, d[i].H, d[i].W, d[i].cin, d[i].cout, d[i].kh, d[i].kw);
+            if (b > pl.bytes_single) pl.bytes_single = b;
+        }
+    }
+    int group = 0;
+    for (int i = 0; i < n; ++i) {
+        if (!ok[i] || taken[i]) continue;
+        const int first = pl.n5;
+        int members = 0;
+        for (int j = i; j < n && members < WG5_MAXB; ++j)
+            if (ok[j] && !taken[j] && key[j] == key[i]) {
+                taken[j] = true;
+                pl.idx[pl.n5] = j; pl.group_of[pl.n5] = group; pl.q[pl.n5] = q[j]; pl.key[pl.n5] = key[j];
+                ++pl.n5; ++members;
+            }
+        int splits[WG5_MAXB];
+        batched_splits(pl.q + first, members, splits);
+        for (int k = 0; k < members; ++k) {
+            Wgrad5Params& qq = pl.q[first + k];
+            qq.splits = splits[k];
+            pl.slab_off[first + k] = pl.bytes5;
+            pl.bytes5 += ((size_t)qq.splits * qq.kh * qq.kw * qq.cin * qq.cout * sizeof(float) + 255) & ~(size_t)255;
+        }
+        ++group;
+    }
+}
+}  // namespace
+
+extern "C" size_t cutie_conv_wgrad_batched_workspace_bytes(const cutie_wgrad_desc* descs, int n, int dtype) {
+    if (!descs || n < 1 || n > CUTIE_MAX_BATCH) return 0;
+    WgradPlan pl;
+    plan_batched(descs, n, dtype, pl);
+    return pl.bytes5 + pl.bytes_single;
+}
+
+extern "C" int cutie_conv_wgrad_batched(const cutie_wgrad_desc* descs, int n, int dtype, void* workspace, size_t workspace_bytes,
+                                        cutie_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    CUTIE_CHECK_ARG(n >= 0 && n <= CUTIE_MAX_BATCH && (n == 0 || descs), "conv_wgrad_batched: n=%d (0..%d)", n, CUTIE_MAX_BATCH);
+    CUTIE_CHECK_ARG(dtype == CUTIE_F32 || dtype == CUTIE_BF16 || dtype == CUTIE_F16, "conv_wgrad_batched: dtype %d", dtype);
+    if (n == 0) return CUTIE_OK;
+    const int es = dtype == CUTIE_F32 ? 4 : 2, epc = 16 / es;
+    for (int i = 0; i < n; ++i) {
+        const cutie_wgrad_desc& d = descs[i];
+        CUTIE_CHECK_ARG(d.B >= 0 && d.H >= 1 && d.W >= 1 && d.cin >= 1 && d.cout >= 1, "conv_wgrad_batched[%d]: bad sizes", i);
+        CUTIE_CHECK_ARG(d.kh >= 1 && d.kw >= 1 && (d.kh & 1) && (d.kw & 1) && d.dil >= 1, "conv_wgrad_batched[%d]: kernel %dx%d dil %d",
+                        i, d.kh, d.kw, d.dil);
+        CUTIE_CHECK_ARG(d.ld_x >= d.cin && d.ld_dz >= d.cout && (d.ld_x * es) % 16 == 0 && (d.ld_dz * es) % 16 == 0,
+                        "conv_wgrad_batched[%d]: rows must be 16-byte multiples (ld_x=%d ld_dz=%d)", i, d.ld_x, d.ld_dz);
+        CUTIE_CHECK_ARG(cutie::cdiv(d.cin, epc) * epc <= d.ld_x && cutie::cdiv(d.cout, epc) * epc <= d.ld_dz,
+                        "conv_wgrad_batched[%d]: ld must cover cin/cout rounded up to %d channels (zero padded)", i, epc);
+        CUTIE_CHECK_ARG(d.dw && (d.B == 0 || (d.x && d.dz && cutie::aligned16(d.x) && cutie::aligned16(d.dz))),
+                        "conv_wgrad_batched[%d]: null or misaligned pointer", i);
+    }
+    WgradPlan pl;
+    plan_batched(descs, n, dtype, pl);
+    if (pl.bytes5 + pl.bytes_single > 0 && (!workspace || workspace_bytes < pl.bytes5 + pl.bytes_single ||
+                                            (reinterpret_cast<uintptr_t>(workspace) & 255))) {
+        cutie::set_error("conv_wgrad_batched: workspace %zu < %zu (or not 256-byte aligned)", workspace_bytes,
+                         pl.bytes5 + pl.bytes_single);
+        return CUTIE_E_WORKSPACE;
+    }
+    char* ws = (char*)workspace;
+    // one launch per kernel instance
+    for (int first = 0; first < pl.n5;) {
+        int last = first;
+        while (last < pl.n5 && pl.group_of[last] == pl.group_of[first]) ++last;
+        Wgrad5Batch bt;
+        bt.n = last - first;
+        bt.gmax = 1;
+        int at = 0;
+        for (int k = first; k < last; ++k) {
+            Wgrad5Params& q = pl.q[k];
+            q.slabs = (float*)(ws + pl.slab_off[k]);
+            bt.p[k - first] = q;
+            bt.pair_start[k - first] = at;
+            at += q.splits;
+            if (q.kh * q.mt * q.ntile > bt.gmax) bt.gmax = q.kh * q.mt * q.ntile;
+        }
+        for (int k = bt.n; k <= WG5_MAXB; ++k) bt.pair_start[k] = at;
+        for (int k = bt.n; k < WG5_MAXB; ++k) bt.p[k] = bt.p[0];
+        const dim3 grid((unsigned)(((at + 7) / 8) * 8 * bt.gmax));
+        wg5_dispatch(dtype, pl.key[first], [&](auto dt, auto kwc, auto maskc, auto narrowc, auto widec) {
+            constexpr auto fn = wgrad5_batched_kernel<decltype(dt)::value, decltype(kwc)::value, decltype(maskc)::value,
+                                                      decltype(narrowc)::value, decltype(widec)::value>;
+            cutie::ensure_dyn_lds((const void*)fn, WG5_LDS);
+            hipLaunchKernelGGL(fn, grid, dim3(WG5_NT), WG5_LDS, stream, bt);
+        });
+        CUTIE_CHECK_LAUNCH();
+        first = last;
+    }
+    // one reduction launch over all of them (WG5_MAXB layers a launch)
+    for (int first = 0; first < pl.n5; first += WG5_MAXB) {
+        const int cnt = pl.n5 - first < WG5_MAXB ? pl.n5 - first : WG5_MAXB;
+        ReduceBatch rb;
+        rb.cnt = cnt;
+        int at = 0;
+        for (int k = 0; k < cnt; ++k) {
+            const Wgrad5Params& q = pl.q[first + k];
+            const cutie_wgrad_desc& d = descs[pl.idx[first + k]];
+            const long long n_w = (long long)q.kh * q.kw * q.cin * q.cout;
+            long long g = cutie::cdiv((n_w & 3) == 0 ? n_w / 4 : n_w, 256);
+            if (g > 2048) g = 2048;
+            rb.slabs[k] = q.slabs; rb.dw[k] = d.dw; rb.n[k] = n_w; rb.splits[k] = q.splits; rb.accumulate[k] = d.accumulate;
+            rb.start[k] = at;
+            at += (int)g;
+        }
+        for (int k = cnt; k <= WG5_MAXB; ++k) rb.start[k] = at;
+        for (int k = cnt; k < WG5_MAXB; ++k) { rb.slabs[k] = nullptr; rb.dw[k] = nullptr; rb.n[k] = 0; rb.splits[k] = 0; rb.accumulate[k] = 0; }
+        hipLaunchKernelGGL(wgrad_reduce_batched_kernel, dim3((unsigned)at), dim3(256), 0, stream, rb);
+        CUTIE_CHECK_LAUNCH();
+    }
+    // what is not a wgrad5 shape (f32, wide kernels), and empty batches: one by one
+    for (int i = 0; i < n; ++i) {
+        bool in5 = false;
+        for (int k = 0; k < pl.n5; ++k) in5 = in5 || pl.idx[k] == i;
+        if (in5) continue;
+        const cutie_wgrad_desc& d = descs[i];
+        const int rc = cutie_conv_wgrad(d.x, d.ld_x, d.cin, d.dz, d.ld_dz, d.cout, d.B, d.H, d.W, d.kh, d.kw, d.dil, d.dw,
+                                        d.accumulate, dtype, ws + pl.bytes5, workspace_bytes - pl.bytes5, stream_);
+        if (rc != CUTIE_OK) return rc;
+    }
     return CUTIE_OK;
 }

@@ -74,6 +74,40 @@ def embed_bwd(ids, dout, dtable, workspace=None):
 
 
 # ------------------------------------------------------------------------------------ K2-K5
+def wgrad_descs(tasks):
+    """tasks: list of (x view [B,H,W,>=cin], cin, dz view [B,H,W,>=cout], cout, kh, kw, dil, dw f32 [kh,kw,cin,cout],
+    accumulate) -> (descriptor array, dtype code); all tasks share one element type"""
+    if not 1 <= len(tasks) <= capi.MAX_BATCH:
+        raise capi.CutieError("conv_wgrad_batched: %d layers (1..%d)" % (len(tasks), capi.MAX_BATCH))
+    arr = (capi.WgradDesc * len(tasks))()
+    dt = None
+    for i, (x, cin, dz, cout, kh, kw, dil, dw, acc) in enumerate(tasks):
+        if dt is None:
+            dt = dt_of(x)
+        if dt_of(x) != dt or dt_of(dz) != dt:
+            raise capi.CutieError("conv_wgrad_batched: one element type per call")
+        if dw.dtype != torch.float32 or not dw.is_contiguous() or tuple(dw.shape) != (kh, kw, cin, cout):
+            raise capi.CutieError("conv_wgrad_batched: dw must be contiguous f32 [kh,kw,cin,cout]")
+        if x.shape[:3] != dz.shape[:3]:
+            raise capi.CutieError("conv_wgrad_batched: x and dz differ in [B,H,W]")
+        d = arr[i]
+        d.x, d.ld_x, d.cin, d.dz, d.ld_dz, d.cout = ptr(x), ld_of(x), cin, ptr(dz), ld_of(dz), cout
+        d.B, d.H, d.W, d.kh, d.kw, d.dil = x.shape[0], x.shape[1], x.shape[2], kh, kw, dil
+        d.dw, d.accumulate = ptr(dw), 1 if acc else 0
+    return arr, dt
+
+
+def conv_wgrad_batched_workspace_bytes(arr, dt):
+    return capi.lib().cutie_conv_wgrad_batched_workspace_bytes(arr, len(arr), dt)
+
+
+def conv_wgrad_batched(arr, dt, workspace):
+    """the weight gradients of several layers in one call (cutie_conv_wgrad_batched): layers on the same kernel instance
+    share one launch with fewer K splits; arr / dt from wgrad_descs (kept by the caller for replay)."""
+    call("cutie_conv_wgrad_batched", arr, len(arr), dt, ptr(workspace), workspace.numel() * workspace.element_size(),
+         stream(workspace.device))
+
+
 def pack_weights(w_hwio, dt, want_fwd=True, want_dgrad=True):
     """f32 [kh,kw,cin,cout] -> (w_fwd [taps,cout,cin_pad], w_dgrad [taps,cin,cout_pad])."""
     kh, kw, cin, cout = w_hwio.shape

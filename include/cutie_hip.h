@@ -216,6 +216,25 @@ int cutie_conv_wgrad(const void* x, int ld_x, int cin, const void* dz, int ld_dz
                      float* dw, int accumulate, int dtype,
                      void* workspace, size_t workspace_bytes, cutie_stream_t stream);
 
+#define CUTIE_MAX_BATCH 32
+/* the weight gradients of up to CUTIE_MAX_BATCH layers in one call (the filter gradients of tf.gradients,
+ * main_train_json.py:152, for several layers of model_framework.py:414-424 at once): layers that run on the same kernel
+ * instance share ONE launch, so 256 CUs are filled by 256 / (sum of the layers' output tiles) K splits instead of
+ * 256 / (one layer's tiles) - a third of the slab bytes and of the reduction reads for three 256->256 layers - and all
+ * reductions are one launch.  Same results as cutie_conv_wgrad up to the order of the f32 slab additions (fixed for a
+ * given set of layers: deterministic).  descs is a HOST array (device pointers inside), copied into the kernel
+ * arguments.  workspace: cutie_conv_wgrad_batched_workspace_bytes(descs, n, dtype) bytes, 256-byte aligned. */
+typedef struct cutie_wgrad_desc {
+    const void* x;  int ld_x, cin;
+    const void* dz; int ld_dz, cout;
+    int B, H, W, kh, kw, dil;
+    float* dw;
+    int accumulate;
+} cutie_wgrad_desc;
+size_t cutie_conv_wgrad_batched_workspace_bytes(const cutie_wgrad_desc* descs /* host */, int n, int dtype);
+int cutie_conv_wgrad_batched(const cutie_wgrad_desc* descs /* host */, int n, int dtype,
+                             void* workspace, size_t workspace_bytes, cutie_stream_t stream);
+
 /* packs f32 HWIO weights [kh*kw][cin][cout] (the layout of '<layer>/weights') into the two
  * operand layouts the conv kernels read: w_fwd [tap][cout][cin_pad] and w_dgrad
  * [tap][cin][cout_pad] (either may be NULL), zero padded, in `dtype`. */
@@ -225,7 +244,6 @@ int cutie_pack_weights(const float* w_hwio, int taps, int cin, int cout,
 
 /* the same for up to CUTIE_MAX_BATCH layers in ONE launch (the per-step repack after Adam:
  * main_train_json.py:156 applies the update, the next forward needs the new operands) */
-#define CUTIE_MAX_BATCH 32
 typedef struct cutie_pack_desc {
     const float* w_hwio;
     void* w_fwd;        /* nullable */

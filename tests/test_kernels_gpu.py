@@ -686,6 +686,54 @@ def test_conv_wgrad(ops, dt, case):
     assert relerr(dw, 2 * w.grad) < (1e-4 if dt == "f32" else 2e-3)
 
 
+@pytest.mark.parametrize("dt", ["f16", "bf16", "f32"])
+def test_conv_wgrad_batched_matches_layer_by_layer(ops, dt):
+    """cutie_conv_wgrad_batched over a mixed bag of layers - three on one kernel instance (one launch, fewer K splits), a
+    dilation-16 layer and a 1x1 layer on instances of their own, a narrow one, one that accumulates - against
+    cutie_conv_wgrad layer by layer: the same sums up to the order of the f32 slab additions, and against float64.
+    f32 is not a batched shape: the call then runs the layers one by one and must give the same bits."""
+    g = torch.Generator().manual_seed(17)
+    tdt = TDT[dt]
+    B, H, W = 4, 32, 64
+    layers = [(128, 256, 3, 5, 1, False), (256, 128, 3, 5, 2, False), (128, 128, 3, 5, 4, True), (128, 128, 3, 5, 16, False),
+              (256, 128, 1, 1, 1, False), (128, 64, 3, 5, 1, False), (64, 18, 1, 1, 1, False)]
+    tasks, singles, refs = [], [], []
+    for cin, cout, kh, kw, dil, acc in layers:
+        x = _rand_act(g, (B, H, W, cin), tdt).to(DEV)
+        ld = (cout + 7) // 8 * 8
+        dz = torch.zeros((B, H, W, ld), dtype=tdt, device=DEV)
+        dz[..., :cout] = _rand_act(g, (B, H, W, cout), tdt).to(DEV)
+        base = torch.randn((kh, kw, cin, cout), generator=g).to(DEV) if acc else torch.full((kh, kw, cin, cout), 7.0, device=DEV)
+        dw_b, dw_s = base.clone(), base.clone()
+        tasks.append((x, cin, dz[..., :cout], cout, kh, kw, dil, dw_b, acc))
+        ws = torch.empty(ops.conv_wgrad_workspace_bytes(B, H, W, cin, cout, kh, kw), dtype=torch.uint8, device=DEV)
+        ops.conv_wgrad(x, cin, dz[..., :cout], cout, kh, kw, dil, dw_s, ws, accumulate=acc)
+        singles.append((dw_s, base if acc else None))
+    arr, dtc = ops.wgrad_descs(tasks)
+    need = ops.conv_wgrad_batched_workspace_bytes(arr, dtc)
+    assert need > 0
+    ws = torch.empty(need, dtype=torch.uint8, device=DEV)
+    for rep in range(2):                     # a second call into the same workspace (the accumulating layer adds again)
+        ops.conv_wgrad_batched(arr, dtc, ws)
+    torch.cuda.synchronize()
+    for (x, cin, dz, cout, kh, kw, dil, dw_b, acc), (dw_s, base) in zip(tasks, singles):
+        if acc:
+            got, want = dw_b - base, 2 * (dw_s - base)
+        else:
+            got, want = dw_b, dw_s
+        if dt == "f32":
+            assert torch.equal(got, want) or acc, (cin, cout, dil)
+        scale = float(want.abs().max())
+        assert float((got - want).abs().max()) <= 2e-5 * scale, (cin, cout, kh, kw, dil)
+    # one layer against float64
+    x, cin, dz, cout, kh, kw, dil, dw_b, _ = tasks[1]
+    w = torch.zeros((kh, kw, cin, cout), dtype=torch.float64, requires_grad=True)
+    (co.conv_raw(x.double().cpu(), w, dil) * dz.double().cpu()).sum().backward()
+    assert relerr(dw_b, w.grad) < (1e-4 if dt == "f32" else 2e-3)
+    with pytest.raises(Exception, match="workspace"):
+        ops.conv_wgrad_batched(arr, dtc, ws[:need // 2])
+
+
 # ------------------------------------------------------------------------------------ K6, K8
 @pytest.mark.parametrize("dt", ["f32", "bf16", "f16"])
 @pytest.mark.parametrize("C", [256, 64, 18])
