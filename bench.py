@@ -53,7 +53,7 @@ class ConvTimer(object):
 
     def __init__(self, ops):
         self.ops, self.orig, self.orig_bwd, self.orig_in_fwd = ops, ops.conv_fwd, ops.conv_dgrad_in_bwd, ops.conv_in_fwd
-        self.events, self.flops, self.enabled = [], [], False
+        self.events, self.flops, self.kinds, self.enabled = [], [], [], False
         ops.conv_fwd = self
         ops.conv_dgrad_in_bwd = self.dgrad_in_bwd
         ops.conv_in_fwd = self.in_fwd
@@ -67,6 +67,7 @@ class ConvTimer(object):
         e1.record()
         self.events.append((e0, e1))
         self.flops.append(conv_launch_flops(segs, y.shape[0], y.shape[1], y.shape[2], n_out))
+        self.kinds.append("forward + instance norm" if r else "forward, then in_apply")
         return r
 
     def dgrad_in_bwd(self, segs, dy, n_out, *a, **kw):
@@ -78,6 +79,7 @@ class ConvTimer(object):
         e1.record()
         self.events.append((e0, e1))
         self.flops.append(conv_launch_flops(segs, dy.shape[0], dy.shape[1], dy.shape[2], n_out))
+        self.kinds.append("data gradient + norm gradient")
         return r
 
     # Timing events serialise the queue (each one is a barrier packet): bracketing all 28 conv
@@ -94,7 +96,20 @@ class ConvTimer(object):
         e1.record()
         self.events.append((e0, e1))
         self.flops.append(conv_launch_flops(segs, out.shape[0], out.shape[1], out.shape[2], n_out))
+        self.kinds.append("conv alone")
         return r
+
+    def by_kind(self, peak_tflops):
+        """the same quotient per kind of bracket: only 'conv alone' is a conv kernel by itself (round 1's figure was all of
+        that kind); the others carry a norm pass or its gradient inside the bracket, which earns no FLOPs"""
+        out = {}
+        for (a, b), fl, kind in zip(self.events, self.flops, self.kinds):
+            e = out.setdefault(kind, [0.0, 0.0, 0])
+            e[0] += a.elapsed_time(b)
+            e[1] += fl
+            e[2] += 1
+        return {k: {"launches": n, "avg_launch_ms": round(ms / n, 4), "frac": round(fl / (ms * 1e-3) / 1e12 / peak_tflops, 4)}
+                for k, (ms, fl, n) in out.items() if ms > 0}
 
     def summary(self):
         ms = [a.elapsed_time(b) for a, b in self.events]
@@ -270,7 +285,7 @@ def main():
             out["roofline"] = {"bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
                                "frac": round(ach / peak, 4), "traffic": traffic, "traffic_source": traffic_src,
                                "kernel": "conv_wide_kernel + conv_kernel (forward + data-gradient implicit GEMM, instance norm / its gradient inside the launch)", "launches": n,
-                               "avg_launch_ms": round(ms / max(n, 1), 4),
+                               "avg_launch_ms": round(ms / max(n, 1), 4), "by_kind": timer.by_kind(peak),
                                "timed_steps": "every %d-th of the %d timed steps%s" % (
                                    ConvTimer.EVERY, args.steps,
                                    ", run on one stream (the others run the weight gradients on a second stream)" if overlap else ""),
