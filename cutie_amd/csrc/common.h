@@ -23,6 +23,7 @@ const Config& config();
 
 // grants `bytes` of dynamic LDS to a kernel on the current device, once (core.hip); returns CUTIE_OK / CUTIE_E_HIP
 int ensure_dyn_lds(const void* fn, int bytes);
+int device_cus();      // compute units of the current device, 0 when unknown
 
 #define CUTIE_CHECK_ARG(cond, ...)                     \
     do {                                               \

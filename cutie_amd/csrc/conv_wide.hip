@@ -805,11 +805,13 @@ bool conv_wide_rendezvous_ok(const ConvParams& p, int bn, int* plain_order) {
     if (!tile_weights(p, weight, wmin, wmax)) return false;
     const int nt = p.tiles_h * p.tiles_w;
     const int per_sample = nt * p.n_tiles_n;
-    if (per_sample > 128) return false;
+    // a sample's workgroups must all be resident at once, one per CU, with room for a second sample beside it
+    if (per_sample > 128 || 2 * per_sample > device_cus()) return false;
     double wavg = 0.0;
     for (int t = 0; t < nt; ++t) wavg += weight[t];
     wavg /= nt;
-    const double rounds = (double)((long long)p.B * per_sample + 255) / 256.0;
+    const int cus = device_cus() > 0 ? device_cus() : 256;
+    const double rounds = (double)((long long)p.B * per_sample + cus - 1) / (double)cus;
     const double step_us = 1.9 * bn / 256.0;
     // every channel lane sweeps the granules of all nt tiles, sixteen tiles in flight at a time (~2 us a batch): the first
     // batch is part of the protocol's measured cost below, the others are not (CUTIE2-dilate 256x128, 128 tiles a sample:
@@ -832,7 +834,7 @@ bool conv_wide_fw_rendezvous_ok(const ConvParams& p, int bn, int* plain_order) {
     if (!tile_weights(p, weight, wmin, wmax)) return false;
     const int nt = p.tiles_h * p.tiles_w;
     const int per_sample = nt * p.n_tiles_n;
-    if (per_sample > 128 || nt > 32) return false;      // more than two batches of granules to sweep cost more than the pass saves
+    if (per_sample > 128 || nt > 32 || 2 * per_sample > device_cus()) return false;      // (nt: more than two batches of granules to sweep cost more than the pass saves)
     double wavg = 0.0;
     for (int t = 0; t < nt; ++t) wavg += weight[t];
     wavg /= nt;

@@ -40,6 +40,23 @@ int ensure_dyn_lds(const void* fn, int bytes) {
     return CUTIE_OK;
 }
 
+// compute units of the current device (cached per device; 0 if the runtime will not say): the tile meeting inside a conv
+// launch needs all workgroups of a sample resident at once - on a partitioned GPU (CPX: 32 CUs) fewer fit than on a whole one
+int device_cus() {
+    static std::mutex mu;
+    static std::vector<int> cus;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0) return 0;
+    std::lock_guard<std::mutex> lock(mu);
+    if ((int)cus.size() <= dev) cus.resize(dev + 1, -1);
+    if (cus[dev] < 0) {
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 0;
+        cus[dev] = n;
+    }
+    return cus[dev];
+}
+
 void set_error(const char* fmt, ...) {
     char buf[1024];
     va_list ap;

@@ -172,11 +172,6 @@ def test_world_size_two_emulated_on_one_gpu(monkeypatch, dtype):
             mode.update(what="apply", store=sent[1 - r], k=0)
             out = trs[r].step({"grid_table": shards[r][0], "gt_classes": shards[r][1]})
             assert mode["k"] == len(sent[1 - r]) and np.isfinite(out["total_loss"])
-        # a + b == b + a, so real replicas stay bit-identical; here a rank's own buffer and the copy of it the other
-        # rank receives come from two RUNS of the same shard, and the embedding gradient's f32 atomics are reproducible
-        # only to rounding (test_forward_is_bit_reproducible_and_backward_nearly): equal to rounding, then
-        apart = float((engs[0].params_flat - engs[1].params_flat).abs().max())
-        assert apart < (5e-7 if dtype == "f32" else 5e-5), (step, apart)
         # the same step by hand: plain-path gradients of the two shards (each with its own wd * w), summed; Adam at 1/2
         gsum, emb_sq = torch.zeros_like(ref.grads_flat), 0.0
         for r in range(2):
@@ -202,12 +197,23 @@ def test_world_size_two_emulated_on_one_gpu(monkeypatch, dtype):
               % (step, rel, worst, int(solid.sum()), solid.numel(), out["global_norm"]))
         print("   norms: replica %.6f by hand %.6f (dense %.6f, embedding rows %.6f)" % (
             out["global_norm"], float(gn.sqrt()) / 2, float((gsum[:ref.n_dense].double() ** 2).sum().sqrt()) / 2, emb_sq ** 0.5 / 2))
+        # a + b == b + a, so real replicas stay bit-identical; here a rank's own buffer and the copy of it the other rank
+        # receives come from two RUNS of the same shard, and the embedding gradient's f32 atomics are reproducible only to
+        # rounding (test_forward_is_bit_reproducible_and_backward_nearly) - which Adam may turn into a step of ~lr where
+        # the gradient itself is at rounding level.  So: equal where the gradient is well determined, close as a whole
+        d01 = (engs[0].params_flat - engs[1].params_flat).double()
+        assert float(d01[solid].abs().max()) < (5e-7 if dtype == "f32" else 5e-5), step
+        assert float(d01.norm() / mv_ref.norm()) < 2e-2, step
         assert rel < (1e-3 if dtype == "f32" else 2e-2), step
         assert worst < (2e-5 if dtype == "f32" else 3e-4), step
         assert abs(out["global_norm"] - float(gn.sqrt()) / 2) < 1e-3 * out["global_norm"]
         # the next step starts from the replicas' state on both sides (m and v are then non-trivial): each step checks the
         # arithmetic of ONE step; left to themselves two trajectories drift apart through ReLU kinks and the hard-negative
         # selection (2.6e-3 of the movement after two steps), which says nothing about the collectives
+        engs[1].params_flat.copy_(engs[0].params_flat)
+        engs[1].repack()
+        trs[1].m.copy_(trs[0].m)
+        trs[1].v.copy_(trs[0].v)
         ref.params_flat.copy_(engs[0].params_flat)
         ref.repack()
         m_ref.copy_(trs[0].m)
