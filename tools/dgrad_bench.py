@@ -2,7 +2,7 @@
 """Data gradient of an instance-normalised 256 -> 256 layer at the bench shape, three ways (dev tool):
   a) cutie_conv_dgrad_in_stats (data gradient + fused sums) followed by cutie_in_bwd_apply   (two-call form)
   b) cutie_conv_dgrad_in_bwd with a sync area                                                (one launch, tiles meet)
-usage: python tools/dgrad_bench.py [dil] [iters]"""
+usage: python tools/dgrad_bench.py [dil] [iters] [KHxKW]"""
 import os
 import sys
 import torch
@@ -11,13 +11,14 @@ from cutie_amd import ops, capi
 
 dil = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 iters = int(sys.argv[2]) if len(sys.argv) > 2 else 30
+KH, KW = (int(v) for v in (sys.argv[3] if len(sys.argv) > 3 else "3x5").split("x"))      # 1x1: the ASPP fan-out data gradients
 B, H, W, C = 32, 64, 64, 256
 dev = "cuda:0"
 g = torch.Generator().manual_seed(0)
 tdt = torch.float16
 dzin = (torch.randn((B, H, W, C), generator=g) * 0.7).to(tdt).to(dev)
 a = torch.relu(torch.randn((B, H, W, C), generator=g) + 0.2).to(tdt).to(dev)
-w = (torch.randn((3, 5, C, C), generator=g) * 0.05).to(dev)
+w = (torch.randn((KH, KW, C, C), generator=g) * 0.05).to(dev)
 _, wd = ops.pack_weights(w, capi.F16, want_fwd=False)
 T = ops.conv_stats_tiles(H, W)
 stats = torch.zeros((B, T, C, 2), device=dev)
@@ -27,7 +28,7 @@ dbp = torch.zeros((B * 32, C), device=dev)
 dy = torch.zeros((B, H, W, C), dtype=tdt, device=dev)
 dz = torch.zeros((B, H, W, C), dtype=tdt, device=dev)
 sync = torch.zeros(ops.conv_sync_bytes(B, T, C) // 4, dtype=torch.int32, device=dev)
-seg = [dict(x=dzin, w=wd, cin=C, kh=3, kw=5, dil=dil, flip=True)]
+seg = [dict(x=dzin, w=wd, cin=C, kh=KH, kw=KW, dil=dil, flip=True)]
 
 
 def two_call():
