@@ -262,7 +262,13 @@ def main():
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    loss = eng.losses(eng._plans[(B, H, W, 0)])
+    plan = eng._plans[(B, H, W, 0)]
+    # a number taken over steps the device declared invalid (a conv tile gave up waiting for its sample's other tiles and
+    # the optimizer skipped the step) or over bad inputs is no measurement: raise instead of printing a line
+    eng.check_inputs(plan)
+    if eng.steps_invalid():
+        raise RuntimeError("%d of the steps were skipped as invalid on the device (late conv tiles): no bench line" % eng.steps_invalid())
+    loss = eng.losses(plan)
 
     if rank == 0:
         docs_per_s = world * B * args.steps / dt
@@ -275,8 +281,8 @@ def main():
                           "global_batch": world * B, "parallelism": "dp%d" % world, "prime_steps": PRIME,
                           "whole_step_mfma_frac": round(docs_per_s / world * GF_PER_DOC_INBOUNDS * 1e9 / (BF16_PEAK_TFLOPS * 1e12), 4),
                           "final_total_loss": round(loss[2], 5)}}
-        if eng.loss_scale is not None:
-            out["config"]["loss_scale"], out["config"]["steps_skipped"] = eng.loss_scale_value()
+        out["config"]["loss_scale"], out["config"]["steps_skipped"] = eng.loss_scale_value()
+        out["config"]["steps_invalid"] = eng.steps_invalid()
         if not args.no_kernel_timing:
             ms, fl, n = timer.summary()
             ach = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
@@ -308,6 +314,9 @@ def main():
             step()
         fence()
         dt16 = time.perf_counter() - t0
+        eng.check_inputs(eng._plans[(B, H, W, 0)])
+        if eng.steps_invalid():
+            raise RuntimeError("%s pass: %d steps skipped as invalid on the device" % (alt, eng.steps_invalid()))
         if use_dist:
             t = torch.tensor([dt16], dtype=torch.float64, device=dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)

@@ -14,6 +14,8 @@ F32, BF16, F16 = 0, 1, 2
 ACT_FROM_Y = 16      # CUTIE_ACT_FROM_Y
 MAX_SEGS = 6
 REDUCE_SCRATCH = 1024
+OPT_SCRATCH = 2048
+LOSS_SCALE_STATE = 8
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CUTIE_HIP_LIB") or os.path.join(_HERE, "libcutie_hip.so")   # override: A/B builds
@@ -65,12 +67,12 @@ SIGNATURES = {
     "cutie_conv_stats_tiles": (_i, [_i, _i]),
     "cutie_conv_fwd": (_i, [_c.POINTER(ConvSeg), _i, _i, _i, _i, _i, _vp, _i, _i, _vp, _i, _vp, _i, _i, _vp]),
     "cutie_conv_in_fwd": (_i, [_c.POINTER(ConvSeg), _i, _i, _i, _i, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _f, _vp, _sz,
-                               _c.POINTER(_i), _i, _vp]),
+                               _vp, _c.POINTER(_i), _i, _vp]),
     "cutie_conv_dgrad_in_stats": (_i, [_c.POINTER(ConvSeg), _i, _i, _i, _i, _i, _vp, _i, _i, _vp, _i, _i, _vp, _i, _f, _vp,
                                        _i, _vp, _i, _i, _vp]),
     "cutie_conv_sync_bytes": (_sz, [_i, _i, _i]),
     "cutie_conv_dgrad_in_bwd": (_i, [_c.POINTER(ConvSeg), _i, _i, _i, _i, _i, _vp, _i, _vp, _i, _vp, _i, _f, _vp, _i, _i,
-                                     _vp, _vp, _i, _vp, _i, _vp, _sz, _i, _vp]),
+                                     _vp, _vp, _i, _vp, _i, _vp, _sz, _vp, _i, _vp]),
     "cutie_conv_wgrad_workspace_bytes": (_sz, [_i, _i, _i, _i, _i, _i, _i]),
     "cutie_conv_wgrad": (_i, [_vp, _i, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _i, _i, _vp, _sz, _vp]),
     "cutie_conv_wgrad_batched_workspace_bytes": (_sz, [_c.POINTER(WgradDesc), _i, _i]),
@@ -91,13 +93,23 @@ SIGNATURES = {
     "cutie_hnm_weights": (_i, [_vp, _vp, _i64, _i, _vp, _vp, _vp, _sz, _vp]),
     "cutie_hnm_weights_static": (_i, [_vp, _vp, _i64, _i, _vp, _vp, _vp]),
     "cutie_softmax_ce_bwd": (_i, [_vp, _vp, _vp, _i64, _i, _vp, _i, _i, _vp, _vp, _vp]),
+    "cutie_head_tiles": (_i, [_i]),
+    "cutie_head_chunks": (_i, [_i]),
+    "cutie_head_workspace_bytes": (_sz, [_i, _i]),
+    "cutie_head_fwd": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _i, _f, _vp, _i, _vp, _i, _vp, _i, _vp, _vp, _i, _vp, _vp,
+                            _vp, _sz, _vp]),
+    "cutie_head_bwd": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _vp, _i, _vp, _i, _i, _i, _f, _vp, _i, _vp, _vp, _vp, _vp,
+                            _vp, _i, _i, _vp, _vp, _sz, _vp]),
     "cutie_ghm_state_bytes": (_sz, [_i]),
     "cutie_ghm_weights": (_i, [_vp, _i, _i, _vp, _i64, _i, _i, _f, _f, _vp, _sz, _vp, _vp, _vp]),
     "cutie_l2_add": (_i, [_vp, _vp, _i64, _f, _vp, _vp, _vp, _vp]),
     "cutie_sumsq": (_i, [_vp, _i64, _i, _vp, _vp, _vp, _vp]),
     "cutie_loss_scale_init": (_i, [_vp, _f, _vp]),
-    "cutie_loss_scale_update": (_i, [_vp, _vp, _f, _f, _i, _f, _f, _vp]),
-    "cutie_adam_step": (_i, [_vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _vp, _f, _f, _i, _vp, _vp]),
+    "cutie_loss_scale_update": (_i, [_vp, _vp, _f, _f, _i, _f, _f, _vp, _vp]),
+    "cutie_adam_step": (_i, [_vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _vp, _f, _f, _i, _vp, _vp, _vp]),
+    "cutie_opt_norm": (_i, [_vp, _vp, _i64, _i64, _f, _vp, _i64, _i, _vp, _vp, _vp]),
+    "cutie_opt_step": (_i, [_vp, _vp, _vp, _vp, _i64, _i64, _f, _f, _c.POINTER(PackDesc), _i, _i, _f, _f, _f, _f, _f, _f, _i,
+                            _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
     "cutie_batch_gather": (_i, [_vp, _i, _i, _vp, _i, _i, _i, _vp, _i, _i, _vp, _vp]),
     "cutie_batch_scatter_add": (_i, [_vp, _i, _i, _vp, _i, _i, _i, _i, _vp, _vp]),
     "cutie_convert": (_i, [_vp, _i, _i, _vp, _i, _i, _i64, _i, _vp]),

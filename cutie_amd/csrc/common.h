@@ -17,7 +17,6 @@ struct Config {
     bool fuse_norm_bwd;   // CUTIE_FUSE_NORM_BWD=0: data gradient and norm-backward sums as two passes
     bool conv_lpt;        // CUTIE_CONV_LPT=0: conv_wide tiles in row-major order
     bool rendezvous;      // CUTIE_RENDEZVOUS=0: cutie_conv_dgrad_in_bwd always as data gradient + cutie_in_bwd_apply
-    bool rv_nowait;       // CUTIE_RV_NOWAIT=1: diagnostic only, invalid results
 };
 const Config& config();
 

@@ -53,11 +53,12 @@ struct ConvParams {
     int rv_dbias_tiles;
     int rv_relu;             // 0 none, 1 ReLU mask a > 0
     int rv_plain_order;      // 1: block ids in launch order (a sample's tiles spread over the XCDs)
-    int rv_nowait;           // diagnostic (CUTIE_RV_NOWAIT=1): do not wait - WRONG results, prices the protocol without the waiting
-    int* rv_err;             // [1]: tiles whose bounded wait ran out (the step's results are then invalid)
+    int* rv_err;             // [1]: waves whose bounded wait ran out (the launch's results are then invalid); word 0 of the sync area
+    int* rv_late;            // [1], nullable: the caller's own counter of the same event (one word for a whole step: the
+                             // optimizer entry points skip the update when it is non-zero)
     // Forward rendezvous (conv_wide only, with stats, nullable): the sample's tiles meet after publishing their moments
     // and `out` receives the NORMALISED activation y = (a - mean) * rsqrt(var + fw_eps); a itself is not stored.
-    // Shares rv_plain_order / rv_nowait / rv_err with the backward form.
+    // Shares rv_plain_order / rv_err / rv_late with the backward form.
     unsigned long long* fw_slots;   // [B][stats_tiles][2][n_out] {value, tag} granules (zeroed once by the caller)
     float fw_eps;
     // conv_wide: order in which an XCD takes the pixel tiles of its samples - heaviest (most live taps)

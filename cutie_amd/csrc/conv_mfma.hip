@@ -31,6 +31,9 @@
 #include "conv_common.h"
 #include <stdlib.h>
 
+#include <mutex>
+#include <vector>
+
 namespace {
 using namespace cutie;
 using namespace cutie::convk;
@@ -833,6 +836,7 @@ struct NormBwd {      // the reduction of cutie_in_bwd_stats, asked of a data-gr
     float* dbias;
     int dbias_tiles;
     unsigned* sync;      // word 0: tiles whose wait ran out; from byte 64: [B][red_tiles][2][n_out] 8-byte granules
+    int* late;           // nullable: the caller's step-wide counter of the same event
 };
 }  // namespace
 
@@ -842,8 +846,30 @@ struct NormFwd {      // cutie_conv_in_fwd: the normalised output, asked of a fo
     int ld_y;
     float eps;
     unsigned* sync;      // word 0: waits that ran out; from byte 64: [B][stats_tiles][2][n_out] 8-byte granules
+    int* late;           // nullable: the caller's step-wide counter of the same event
 };
 }  // namespace
+
+// A sync area belongs to ONE (B, slot tiles, n_out): the tiles of a launch derive its tag from their own slots, which only
+// agree when every earlier launch on the area had the same geometry.  The library cannot read device memory here, so it
+// keeps the geometry each area was last used with on the host and clears the area (on the launch stream) when a call
+// brings another one - a caller that reuses a buffer for a second layer or shape gets a fresh area instead of tiles that
+// wait for tags nobody writes.
+static int sync_area_claim(void* sync, size_t bytes, int B, int tiles, int n_out, hipStream_t stream) {
+    struct Entry { const void* p; int B, tiles, n_out; };
+    static std::mutex mu;
+    static std::vector<Entry> seen;
+    std::lock_guard<std::mutex> lock(mu);
+    for (Entry& e : seen) {
+        if (e.p != sync) continue;
+        if (e.B == B && e.tiles == tiles && e.n_out == n_out) return CUTIE_OK;
+        CUTIE_CHECK_HIP(hipMemsetAsync(sync, 0, bytes, stream));
+        e.B = B; e.tiles = tiles; e.n_out = n_out;
+        return CUTIE_OK;
+    }
+    seen.push_back({sync, B, tiles, n_out});      // first sight: zeroed by the caller (the documented contract)
+    return CUTIE_OK;
+}
 
 static int conv_fwd_impl(const cutie_conv_seg* segs, int n_segs, int B, int H, int W, int n_out, void* out,
                          int ld_out, int out_dtype, const float* bias, int relu, float* stats, int stats_tiles,
@@ -864,7 +890,7 @@ static int conv_fwd_impl(const cutie_conv_seg* segs, int n_segs, int B, int H, i
     ConvParams p;
     p.nseg = n_segs;
     p.bw_a = nullptr; p.bw_ld_a = 0; p.bw_stats = nullptr; p.bw_stats_tiles = 0; p.bw_eps = 0.f; p.bw_bias = nullptr; p.bw_act = 0; p.bw_red = nullptr; p.bw_red_tiles = 0; p.perm_n = 0;
-    p.rv_slots = nullptr; p.rv_dz = nullptr; p.rv_ld_dz = 0; p.rv_dbias = nullptr; p.rv_dbias_tiles = 0; p.rv_relu = 0; p.rv_plain_order = 0; p.rv_err = nullptr; p.rv_nowait = 0; p.fw_slots = nullptr; p.fw_eps = 0.f;
+    p.rv_slots = nullptr; p.rv_dz = nullptr; p.rv_ld_dz = 0; p.rv_dbias = nullptr; p.rv_dbias_tiles = 0; p.rv_relu = 0; p.rv_plain_order = 0; p.rv_err = nullptr; p.rv_late = nullptr; p.fw_slots = nullptr; p.fw_eps = 0.f;
     int twb, th_g;
     generic_tiling(W, th_g, twb);
     p.TWB = twb;
@@ -936,7 +962,7 @@ static int conv_fwd_impl(const cutie_conv_seg* segs, int n_segs, int B, int H, i
                     q.rv_err = reinterpret_cast<int*>(nb->sync);      // word 0: timeouts; the granules start 64 bytes in
                     q.rv_slots = reinterpret_cast<unsigned long long*>(nb->sync + 16);
                     q.rv_dz = (char*)nb->dz; q.rv_ld_dz = nb->ld_dz; q.rv_dbias = nb->dbias; q.rv_dbias_tiles = nb->dbias_tiles;
-                    q.rv_relu = nb->relu & 15; q.rv_plain_order = plain; q.rv_nowait = cutie::config().rv_nowait ? 1 : 0;
+                    q.rv_relu = nb->relu & 15; q.rv_plain_order = plain; q.rv_late = nb->late;
                 }
             }
             if (nf && !nb && stats && cutie::config().rendezvous && relu != 2 && (nf->ld_y * 2) % 16 == 0 && cutie::aligned16(nf->y)) {
@@ -944,8 +970,7 @@ static int conv_fwd_impl(const cutie_conv_seg* segs, int n_segs, int B, int H, i
                 if (cutie::conv_wide_fw_rendezvous_ok(q, bn, &plain)) {      // the tiles meet: y goes out, a does not
                     q.out = (char*)nf->y; q.ld_out = nf->ld_y;
                     q.fw_slots = reinterpret_cast<unsigned long long*>(nf->sync + 16); q.fw_eps = nf->eps;
-                    q.rv_err = reinterpret_cast<int*>(nf->sync); q.rv_plain_order = plain;
-                    q.rv_nowait = cutie::config().rv_nowait ? 1 : 0;
+                    q.rv_err = reinterpret_cast<int*>(nf->sync); q.rv_plain_order = plain; q.rv_late = nf->late;
                     meet = true;
                 }
             }
@@ -984,7 +1009,8 @@ extern "C" int cutie_conv_fwd(const cutie_conv_seg* segs, int n_segs, int B, int
 
 extern "C" int cutie_conv_in_fwd(const cutie_conv_seg* segs, int n_segs, int B, int H, int W, int n_out, void* a, int ld_a,
                                  void* y, int ld_y, const float* bias, int relu, float* stats, int stats_tiles, float eps,
-                                 void* sync, size_t sync_bytes, int* fused, int dtype, cutie_stream_t stream_) {
+                                 void* sync, size_t sync_bytes, int32_t* late_count, int* fused, int dtype,
+                                 cutie_stream_t stream_) {
     CUTIE_CHECK_ARG(B >= 0 && H >= 1 && W >= 1 && n_out >= 1, "conv_in_fwd: bad sizes");
     if (fused) *fused = 0;
     if (B == 0) return CUTIE_OK;
@@ -994,7 +1020,10 @@ extern "C" int cutie_conv_in_fwd(const cutie_conv_seg* segs, int n_segs, int B, 
                          cutie_conv_sync_bytes(B, stats_tiles, n_out));
         return CUTIE_E_WORKSPACE;
     }
-    const NormFwd nf = {y, ld_y, eps, (unsigned*)sync};
+    if (sync) {
+        if (int e = sync_area_claim(sync, cutie_conv_sync_bytes(B, stats_tiles, n_out), B, stats_tiles, n_out, (hipStream_t)stream_)) return e;
+    }
+    const NormFwd nf = {y, ld_y, eps, (unsigned*)sync, late_count};
     const int rc = conv_fwd_impl(segs, n_segs, B, H, W, n_out, a, ld_a, dtype, bias, relu, stats, stats_tiles, dtype, nullptr,
                                  stream_, sync ? &nf : nullptr);
     if (rc == 1) {      // one launch did all of it; `a` was not written
@@ -1018,7 +1047,7 @@ extern "C" int cutie_conv_dgrad_in_stats(const cutie_conv_seg* segs, int n_segs,
     CUTIE_CHECK_ARG((reinterpret_cast<uintptr_t>(stats) & 7) == 0 && (reinterpret_cast<uintptr_t>(red) & 7) == 0,
                     "conv_dgrad_in_stats: stats and red must be 8-byte aligned");
     const NormBwd nb = {a, ld_a, a_dtype, stats, stats_tiles, eps, red, red_tiles, shift_bias, shift_act,
-                        nullptr, 0, 0, nullptr, 0, nullptr};
+                        nullptr, 0, 0, nullptr, 0, nullptr, nullptr};
     return conv_fwd_impl(segs, n_segs, B, H, W, n_out, out, ld_out, out_dtype, nullptr, 0, nullptr, 0, dtype, &nb, stream_);
 }
 
@@ -1030,8 +1059,8 @@ extern "C" size_t cutie_conv_sync_bytes(int B, int red_tiles, int n_out) {
 extern "C" int cutie_conv_dgrad_in_bwd(const cutie_conv_seg* segs, int n_segs, int B, int H, int W, int n_out, void* dy,
                                        int ld_dy, const void* a, int ld_a, const float* stats, int stats_tiles, float eps,
                                        float* red, int red_tiles, int relu, const float* shift_bias, void* dz, int ld_dz,
-                                       float* dbias_part, int dbias_tiles, void* sync, size_t sync_bytes, int dtype,
-                                       cutie_stream_t stream_) {
+                                       float* dbias_part, int dbias_tiles, void* sync, size_t sync_bytes,
+                                       int32_t* late_count, int dtype, cutie_stream_t stream_) {
     CUTIE_CHECK_ARG(B >= 0 && H >= 1 && W >= 1 && n_out >= 1, "conv_dgrad_in_bwd: bad sizes");
     if (B == 0) return CUTIE_OK;
     CUTIE_CHECK_ARG(dy && a && stats && red && dz && ld_dy >= n_out && ld_a >= n_out && ld_dz >= n_out,
@@ -1048,8 +1077,11 @@ extern "C" int cutie_conv_dgrad_in_bwd(const cutie_conv_seg* segs, int n_segs, i
                          cutie_conv_sync_bytes(B, red_tiles, n_out));
         return CUTIE_E_WORKSPACE;
     }
+    if (sync) {
+        if (int e = sync_area_claim(sync, cutie_conv_sync_bytes(B, red_tiles, n_out), B, red_tiles, n_out, (hipStream_t)stream_)) return e;
+    }
     const NormBwd nb = {a, ld_a, dtype, stats, stats_tiles, eps, red, red_tiles, shift_bias, relu, dz, ld_dz, relu, dbias_part,
-                        dbias_tiles, (unsigned*)sync};
+                        dbias_tiles, (unsigned*)sync, late_count};
     const int rc = conv_fwd_impl(segs, n_segs, B, H, W, n_out, dy, ld_dy, dtype, nullptr, 0, nullptr, 0, dtype, &nb, stream_);
     if (rc == 1) return CUTIE_OK;      // one launch did all of it
     if (rc != CUTIE_OK) return rc;

@@ -75,7 +75,7 @@ __device__ __forceinline__ void granule_publish(unsigned long long* slots, int b
     __hip_atomic_store(g1 + n_out, ((unsigned long long)tag << 32) | __float_as_uint(s2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 __device__ __forceinline__ void granule_sweep(const unsigned long long* slots, int b, int slot_tiles, int T, int n_out, int c,
-                                              unsigned tag, int nowait, int* err, float& r1, float& r2) {
+                                              unsigned tag, int* err, int* err2, float& r1, float& r2) {
     const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();      // 100 MHz
     bool late = false;
     while (true) {
@@ -100,14 +100,22 @@ __device__ __forceinline__ void granule_sweep(const unsigned long long* slots, i
                 }
             }
         }
-        if (all || nowait) break;
+#ifdef CW_DIAG_NOWAIT      // diagnostic build only (tools/build_variant.sh): prices the protocol without the waiting - WRONG results
+        break;
+#endif
+        if (all) break;
         if (__builtin_amdgcn_s_memrealtime() - t0 > 20000000ull) {      // 0.2 s: the other tiles never came
             late = true;
             break;
         }
         __builtin_amdgcn_s_sleep(4);
     }
-    if (late && (threadIdx.x & 63) == 0) atomicAdd(err, 1);
+    // a wait that ran out: the sums folded above are incomplete and what this tile stores is wrong.  Counted in the
+    // sync area's word 0 and in the caller's step-wide word, which gates the optimizer (cutie_opt_step / cutie_adam_step)
+    if (late && (threadIdx.x & 63) == 0) {
+        atomicAdd(err, 1);
+        if (err2) atomicAdd(err2, 1);
+    }
 }
 
 // element offset of (pixel row, channel) in the staged output tile: [256][BN] with the 16-byte chunk index XORed by the
@@ -297,7 +305,7 @@ __device__ __forceinline__ void conv_wide_epilogue(const ConvParams& p, float4_t
             // arithmetic of norm.hip's fold_slots<1>) - this lane then knows its channel's mean and 1/sigma
             granule_publish(p.fw_slots, b, p.stats_tiles, tile, n_out, n0 + tid, fw_tag, s1, s2);
             float r1, r2;
-            granule_sweep(p.fw_slots, b, p.stats_tiles, p.tiles_h * p.tiles_w, n_out, n0 + tid, fw_tag, p.rv_nowait, p.rv_err, r1, r2);
+            granule_sweep(p.fw_slots, b, p.stats_tiles, p.tiles_h * p.tiles_w, n_out, n0 + tid, fw_tag, p.rv_err, p.rv_late, r1, r2);
             const float inv_n = 1.f / (float)(H * W);
             norm_mean_inv(r1, r2, inv_n, norm_shift(p.bias, p.relu, n0 + tid), p.fw_eps, tab[tid], tab[BN + tid]);
         }
@@ -408,7 +416,7 @@ __device__ __forceinline__ void conv_wide_epilogue(const ConvParams& p, float4_t
     if (tid < BN && n0 + tid < n_out) {
         const float inv_n = 1.f / (float)(H * W);
         float r1, r2;
-        granule_sweep(p.rv_slots, b, p.bw_red_tiles, T, n_out, n0 + tid, rv_tag, p.rv_nowait, p.rv_err, r1, r2);
+        granule_sweep(p.rv_slots, b, p.bw_red_tiles, T, n_out, n0 + tid, rv_tag, p.rv_err, p.rv_late, r1, r2);
         tab2[tid] = r1 * inv_n;
         tab2[BN + tid] = r2 * inv_n;
     }

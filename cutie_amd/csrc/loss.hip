@@ -149,26 +149,34 @@ __device__ __forceinline__ long long hnm_num_bg(const int* counts, int ratio, bo
 }
 
 // Which bin holds the k-th largest key (k >= 1), and how many of that bin's keys are wanted.
-// All 256 lanes take part; hist has `bins` (a multiple of 256) entries.  sh: 260 ints.
+// All 256 lanes take part; hist has `bins` (a multiple of 256) entries.  sh: 264 ints.
+// Lane t owns bins [t*per, (t+1)*per); a suffix scan over the 256 lane sums (shuffles inside a wave, the four wave
+// totals through LDS) finds the one lane whose bins hold rank k from the top, and that lane walks its own `per` bins.
+// (Round 2 walked the 256 lane sums on ONE lane - a chain of dependent LDS reads that was most of the 10 us each of
+// these launch-floor kernels took.)
 __device__ __forceinline__ void hnm_select(const int* __restrict__ hist, int bins, long long k, int* sh, int& bin,
                                            long long& k_in) {
     const int per = bins / HNM_T;
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     int mine = 0;
     for (int i = 0; i < per; ++i) mine += hist[tid * per + i];
+    int incl = mine;                              // sum over lanes >= mine inside the wave
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int u = __shfl_down(incl, o, 64);
+        if (lane + o < 64) incl += u;
+    }
     __syncthreads();
-    sh[tid] = mine;
+    if (lane == 0) sh[258 + wv] = incl;
+    if (tid == 0) { sh[256] = 0; sh[257] = 0; }
     __syncthreads();
-    if (tid == 0) {
-        // walk the lane sums from the top bin down, then the bins of the lane that holds rank k
-        long long rem = k;
-        int t = HNM_T - 1;
-        for (; t > 0; --t) {
-            if (rem <= sh[t]) break;
-            rem -= sh[t];
-        }
-        int bsel = t * per + per - 1;
-        for (; bsel > t * per; --bsel) {
+    long long above = 0;                          // keys in the waves above this one
+    for (int w = wv + 1; w < HNM_T / 64; ++w) above += sh[258 + w];
+    const long long hi = above + incl, lo = hi - mine;      // keys in bins >= mine / > mine
+    if (lo < k && k <= hi) {
+        long long rem = k - lo;
+        int bsel = tid * per + per - 1;
+        for (; bsel > tid * per; --bsel) {
             const int h = hist[bsel];
             if (rem <= h) break;
             rem -= h;
@@ -182,9 +190,27 @@ __device__ __forceinline__ void hnm_select(const int* __restrict__ hist, int bin
     __syncthreads();
 }
 
+// Cells of the flattened batch as 1024-cell chunks that never straddle a sample: chunk (b, cs) covers cells
+// b*HW + cs*1024 .. of sample b (the last chunk of a sample may be short).  Chunk ids grow with the cell index, so
+// "index order" is chunk order, then position.  The flat entry points run with one sample of n_cells cells.
+struct CellMap {
+    long long HW;
+    int cps;           // chunks per sample
+};
+__device__ __forceinline__ long long chunk_cell(const CellMap& cm, int chunk, int pos, bool& valid) {
+    const int b = chunk / cm.cps, cs = chunk - b * cm.cps;
+    const long long local = (long long)cs * HNM_CHUNK + pos;
+    valid = local < cm.HW;
+    return (long long)b * cm.HW + local;
+}
+// labels as the loader's int8 grid (data_loader_json.py:455) or as int32
+__device__ __forceinline__ int label_at(const void* labels, int label_bytes, long long i) {
+    return label_bytes == 1 ? (int)reinterpret_cast<const int8_t*>(labels)[i] : reinterpret_cast<const int32_t*>(labels)[i];
+}
+
 // level 0: counts, foreground ce partial sums, histogram of the top 11 key bits of background cells
-__global__ __launch_bounds__(HNM_T) void hnm_count_kernel(const float* __restrict__ ce, const int32_t* __restrict__ labels,
-                                                          int64_t n_cells, int chunks, void* ws_) {
+__global__ __launch_bounds__(HNM_T) void hnm_count_kernel(const float* __restrict__ ce, const void* __restrict__ labels,
+                                                          int label_bytes, CellMap cm, int chunks, void* ws_) {
     __shared__ int hist[HNM_B0];
     __shared__ int shi[4];
     __shared__ float shf[4];
@@ -194,13 +220,13 @@ __global__ __launch_bounds__(HNM_T) void hnm_count_kernel(const float* __restric
     __syncthreads();
     int nfg = 0, nbg = 0;
     float sum_fg = 0.f;
-    const int64_t base = (int64_t)blockIdx.x * HNM_CHUNK;
 #pragma unroll
     for (int u = 0; u < HNM_CHUNK / HNM_T; ++u) {
-        const int64_t i = base + u * HNM_T + tid;
-        if (i < n_cells) {
+        bool in;
+        const long long i = chunk_cell(cm, blockIdx.x, u * HNM_T + tid, in);
+        if (in) {
             const float c = ce[i];
-            if (labels[i] != 0) { ++nfg; sum_fg += c; }
+            if (label_at(labels, label_bytes, i) != 0) { ++nfg; sum_fg += c; }
             else { ++nbg; atomicAdd(&hist[sortable(c) >> 21], 1); }
         }
     }
@@ -219,11 +245,11 @@ __global__ __launch_bounds__(HNM_T) void hnm_count_kernel(const float* __restric
 // level 1 / 2: redo the previous level's bin selection, histogram the next key bits of the
 // background cells inside the selected prefix
 template <int LEVEL>
-__global__ __launch_bounds__(HNM_T) void hnm_hist_kernel(const float* __restrict__ ce, const int32_t* __restrict__ labels,
-                                                         int64_t n_cells, int chunks, int ratio, void* ws_) {
+__global__ __launch_bounds__(HNM_T) void hnm_hist_kernel(const float* __restrict__ ce, const void* __restrict__ labels,
+                                                         int label_bytes, CellMap cm, int chunks, int ratio, void* ws_) {
     constexpr int BINS = LEVEL == 1 ? HNM_B1 : HNM_B2;
     __shared__ int hist[BINS];
-    __shared__ int sh[260];
+    __shared__ int sh[264];
     const HnmWs ws = hnm_ws(ws_, chunks);
     const int tid = threadIdx.x;
     bool all_bg;
@@ -244,11 +270,11 @@ __global__ __launch_bounds__(HNM_T) void hnm_hist_kernel(const float* __restrict
     }
     for (int i = tid; i < BINS; i += HNM_T) hist[i] = 0;
     __syncthreads();
-    const int64_t base = (int64_t)blockIdx.x * HNM_CHUNK;
 #pragma unroll
     for (int u = 0; u < HNM_CHUNK / HNM_T; ++u) {
-        const int64_t i = base + u * HNM_T + tid;
-        if (i < n_cells && labels[i] == 0) {
+        bool in;
+        const long long i = chunk_cell(cm, blockIdx.x, u * HNM_T + tid, in);
+        if (in && label_at(labels, label_bytes, i) == 0) {
             const unsigned key = sortable(ce[i]);
             if (LEVEL == 1) {
                 if ((key >> 21) == prefix) atomicAdd(&hist[(key >> 10) & 2047], 1);
@@ -264,9 +290,9 @@ __global__ __launch_bounds__(HNM_T) void hnm_hist_kernel(const float* __restrict
 }
 
 // threshold key and the number of cells equal to it that are selected; per-chunk tie counts
-__global__ __launch_bounds__(HNM_T) void hnm_tie_kernel(const float* __restrict__ ce, const int32_t* __restrict__ labels,
-                                                        int64_t n_cells, int chunks, int ratio, void* ws_) {
-    __shared__ int sh[260];
+__global__ __launch_bounds__(HNM_T) void hnm_tie_kernel(const float* __restrict__ ce, const void* __restrict__ labels,
+                                                        int label_bytes, CellMap cm, int chunks, int ratio, void* ws_) {
+    __shared__ int sh[264];
     __shared__ int shi[4];
     const HnmWs ws = hnm_ws(ws_, chunks);
     const int tid = threadIdx.x;
@@ -278,23 +304,36 @@ __global__ __launch_bounds__(HNM_T) void hnm_tie_kernel(const float* __restrict_
     const unsigned thr = ((unsigned)ws.counts[2] << 21) | ((unsigned)ws.counts[4] << 10) | (unsigned)b2;
     if (blockIdx.x == 0 && tid == 0) { ws.counts[6] = (int)thr; ws.counts[7] = (int)k_eq; }
     int ties = 0;
-    const int64_t base = (int64_t)blockIdx.x * HNM_CHUNK;
 #pragma unroll
     for (int u = 0; u < HNM_CHUNK / HNM_T; ++u) {
-        const int64_t i = base + u * HNM_T + tid;
-        if (i < n_cells && labels[i] == 0 && sortable(ce[i]) == thr) ++ties;
+        bool in;
+        const long long i = chunk_cell(cm, blockIdx.x, u * HNM_T + tid, in);
+        if (in && label_at(labels, label_bytes, i) == 0 && sortable(ce[i]) == thr) ++ties;
     }
     ties = block_sum_i256(ties, shi);
     if (tid == 0) ws.tie_cnt[blockIdx.x] = ties;
 }
 
+// The logits head's backward reduction, optionally taken by hnm_weight_kernel while it has the cell weights at hand:
+// dy[n][c] = S * w[n] * (probs[n][c] - [c == label]) is the gradient of the loss in the instance-normalised logits y
+// (cutie_softmax_ce_bwd); the norm's backward needs (sum dy, sum dy * y) per (sample, class): chunk (b, cs) STORES its
+// share into red[b][cs][c][2].  Eight lanes share a cell, four classes each (C <= 32).
+struct HeadRed {
+    const float* probs;      // [N][C]
+    const float* logits;     // [N][ld_l], the normalised logits = xhat
+    int ld_l, C;
+    const float* loss_scale; // nullable
+    float* red;              // [B][cps][C][2]; null = no reduction (the plain cutie_hnm_weights)
+};
+
 // per-cell weights (1/nfg, 1/num_bg or 0) and the per-chunk sums of the selected background ce
-__global__ __launch_bounds__(HNM_T) void hnm_weight_kernel(const float* __restrict__ ce, const int32_t* __restrict__ labels,
-                                                           int64_t n_cells, int chunks, int ratio, void* ws_,
-                                                           float* __restrict__ weight) {
+__global__ __launch_bounds__(HNM_T) void hnm_weight_kernel(const float* __restrict__ ce, const void* __restrict__ labels,
+                                                           int label_bytes, CellMap cm, int chunks, int ratio, void* ws_,
+                                                           float* __restrict__ weight, HeadRed hr) {
     __shared__ int shi[4];
     __shared__ float shf[4];
     __shared__ int wave_cnt[4];
+    __shared__ float wsh[HNM_CHUNK];
     const HnmWs ws = hnm_ws(ws_, chunks);
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     bool all_bg;
@@ -312,11 +351,10 @@ __global__ __launch_bounds__(HNM_T) void hnm_weight_kernel(const float* __restri
     const float w_fg = 1.f / (float)ws.counts[0];          // inf when nfg == 0; unused then
     const float w_bg = 1.f / (float)num_bg;
     float sum_sel = 0.f;
-    const int64_t base = (int64_t)blockIdx.x * HNM_CHUNK;
     for (int u = 0; u < HNM_CHUNK / HNM_T; ++u) {
-        const int64_t i = base + u * HNM_T + tid;
-        const bool in = i < n_cells;
-        const int lab = in ? labels[i] : 1;
+        bool in;
+        const long long i = chunk_cell(cm, blockIdx.x, u * HNM_T + tid, in);
+        const int lab = in ? label_at(labels, label_bytes, i) : 1;
         const float c = in ? ce[i] : 0.f;
         const bool bg = in && lab == 0;
         bool take = false, eq = false;
@@ -342,20 +380,54 @@ __global__ __launch_bounds__(HNM_T) void hnm_weight_kernel(const float* __restri
             if (eq && before_chunk + wave_off + before < k_eq) take = true;
             before_chunk += total;
         }
+        float w = 0.f;
         if (in) {
-            float w = 0.f;
             if (lab != 0) w = w_fg;
             else if (take) { w = w_bg; sum_sel += c; }
             weight[i] = w;
         }
+        wsh[u * HNM_T + tid] = w;
     }
     sum_sel = block_sum_f256(sum_sel, shf);
     if (tid == 0) ws.sum_sel[blockIdx.x] = sum_sel;
+    if (!hr.red) return;
+    // ---- (sum dy, sum dy * y) of this chunk: lane = (cell slot g, class quad q); cells without a weight have dy = 0
+    __shared__ float racc[32][32][2];      // [cell slot][class]
+    __syncthreads();                       // wsh is complete
+    const int q = tid & 7, g = tid >> 3;
+    const float S = hr.loss_scale ? hr.loss_scale[0] : 1.f;
+    float r1[4] = {0.f, 0.f, 0.f, 0.f}, r2[4] = {0.f, 0.f, 0.f, 0.f};
+    if (q * 4 < hr.C) {
+        for (int pass = 0; pass < HNM_CHUNK / 32; ++pass) {
+            const float w = wsh[pass * 32 + g];
+            if (w == 0.f) continue;
+            bool in;
+            const long long i = chunk_cell(cm, blockIdx.x, pass * 32 + g, in);
+            const int lab = label_at(labels, label_bytes, i);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int c = q * 4 + e;
+                if (c < hr.C) {
+                    const float dy = S * w * (hr.probs[i * hr.C + c] - (lab == c ? 1.f : 0.f));
+                    r1[e] += dy;
+                    r2[e] = __builtin_fmaf(dy, hr.logits[i * hr.ld_l + c], r2[e]);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { racc[g][q * 4 + e][0] = r1[e]; racc[g][q * 4 + e][1] = r2[e]; }
+    __syncthreads();
+    if (tid < 2 * hr.C) {
+        const int c = tid >> 1, k = tid & 1;
+        float t = 0.f;
+#pragma unroll 8
+        for (int r = 0; r < 32; ++r) t += racc[r][c][k];      // fixed order
+        hr.red[((long long)blockIdx.x * hr.C + c) * 2 + k] = t;
+    }
 }
 
-__global__ __launch_bounds__(64) void hnm_final_kernel(int chunks, int ratio, void* ws_, float* __restrict__ loss_out) {
-    const HnmWs ws = hnm_ws(ws_, chunks);
-    if (threadIdx.x != 0) return;
+__device__ __forceinline__ void hnm_final(const HnmWs& ws, int chunks, int ratio, float* __restrict__ loss_out) {
     bool all_bg;
     const long long num_bg = hnm_num_bg(ws.counts, ratio, all_bg);
     float sum_fg = 0.f, sum_sel = 0.f;
@@ -364,6 +436,12 @@ __global__ __launch_bounds__(64) void hnm_final_kernel(int chunks, int ratio, vo
     loss_out[0] = sum_fg / (float)ws.counts[0] + sum_sel / (float)num_bg;
     loss_out[1] = (float)ws.counts[0];
     loss_out[2] = (float)num_bg;
+}
+
+__global__ __launch_bounds__(64) void hnm_final_kernel(int chunks, int ratio, void* ws_, float* __restrict__ loss_out) {
+    const HnmWs ws = hnm_ws(ws_, chunks);
+    if (threadIdx.x != 0) return;
+    hnm_final(ws, chunks, ratio, loss_out);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -435,6 +513,305 @@ __global__ __launch_bounds__(256) void ghm_apply_kernel(const TL* __restrict__ l
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// The logits head as a handful of small launches (round 2 took fourteen, ~155 us for 0.3 GFLOP):
+//   cls_logits = Model.conv(1, 1, C) + bias + ReLU + instance norm   (model_cutie_aspp.py:72-73, model_framework.py:414-424)
+//   softmax (model_framework.py:318-320), sparse softmax CE + hard negative mining (model_cutie.py:107-130)
+// forward:  head_conv_kernel     a = relu(x W + b) in f32 (MFMA, one 256-pixel tile per workgroup) + the tile's moments
+//           head_norm_ce_kernel  y = instance_norm(a), softmax, CE by wavefront reduction (eight lanes share a cell),
+//                                and level 0 of the hard-negative select (counts, foreground CE sums, first histogram)
+// backward: hnm_hist<1>, hnm_hist<2>, hnm_tie, hnm_weight (+ the norm gradient's two sums), head_bwd_kernel
+//           (dz of the logits layer, its bias-gradient partials, the loss)
+typedef __attribute__((ext_vector_type(8))) short hd_short8_t;
+typedef __attribute__((ext_vector_type(4))) float hd_float4_t;
+typedef _Float16 hd_half8_t __attribute__((ext_vector_type(8)));
+constexpr int HEAD_TILE = 256;        // pixels per head_conv workgroup
+constexpr int HEAD_MAX_KK = 8;        // cin <= 256
+
+template <int DT>
+__device__ __forceinline__ hd_float4_t head_mma(const uint4& a, const uint4& b, hd_float4_t c) {
+    if constexpr (DT == CUTIE_BF16) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(hd_short8_t, a), __builtin_bit_cast(hd_short8_t, b), c, 0, 0, 0);
+    } else {
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(hd_half8_t, a), __builtin_bit_cast(hd_half8_t, b), c, 0, 0, 0);
+    }
+}
+__device__ __forceinline__ float hd_row16_sum(float v) {      // sum over the 16 lanes of a DPP row
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));
+    return v;
+}
+
+// grid (tiles per sample, B); 256 lanes = 4 waves x 64 pixels.  The MFMAs take the weight fragment as the row operand:
+// lane (li, lg) of accumulator [m][nb] holds pixel m*16 + li and the four classes nb*16 + lg*4 .. +3.
+template <int DT>
+__global__ __launch_bounds__(256) void head_conv_kernel(const typename elem<DT>::type* __restrict__ x, int ld_x, int HW, int cin,
+                                                        const float* __restrict__ w, const float* __restrict__ bias, int C,
+                                                        float* __restrict__ a, int ld_a, float* __restrict__ stats, int tiles) {
+    typedef typename elem<DT>::type T;
+    __shared__ uint4 wf[2][HEAD_MAX_KK][64];
+    __shared__ float2 wsum[4][32];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, lg = lane >> 4;
+    const int KK = cin >> 5;
+    for (int idx = tid; idx < 2 * KK * 64; idx += 256) {
+        const int ln = idx & 63, kk = (idx >> 6) % KK, nb = idx / (64 * KK);
+        const int n = nb * 16 + (ln & 15), k0 = kk * 32 + (ln >> 4) * 8;
+        T h[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) store_from_f32(&h[j], n < C ? w[(long long)(k0 + j) * C + n] : 0.f);
+        wf[nb][kk][ln] = *reinterpret_cast<const uint4*>(h);
+    }
+    __syncthreads();
+    const int b = blockIdx.y;
+    const int p0 = blockIdx.x * HEAD_TILE + wave * 64;
+    hd_float4_t acc[4][2];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) { acc[m][0] = hd_float4_t{0.f, 0.f, 0.f, 0.f}; acc[m][1] = hd_float4_t{0.f, 0.f, 0.f, 0.f}; }
+    for (int kk = 0; kk < KK; ++kk) {
+        uint4 xf[4];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            const int px = p0 + m * 16 + li;
+            xf[m] = make_uint4(0u, 0u, 0u, 0u);
+            if (px < HW) xf[m] = *reinterpret_cast<const uint4*>(x + ((long long)b * HW + px) * ld_x + kk * 32 + lg * 8);
+        }
+        const uint4 w0 = wf[0][kk][lane], w1 = wf[1][kk][lane];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            acc[m][0] = head_mma<DT>(w0, xf[m], acc[m][0]);
+            acc[m][1] = head_mma<DT>(w1, xf[m], acc[m][1]);
+        }
+    }
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb) {
+        const int cb = nb * 16 + lg * 4;
+        float bv[4], sh[4], s1[4], s2[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            bv[r] = cb + r < C ? bias[cb + r] : 0.f;
+            sh[r] = fmaxf(bv[r], 0.f);          // norm_shift(bias, ReLU, c): the moments are kept about it
+            s1[r] = 0.f;
+            s2[r] = 0.f;
+        }
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            const int px = p0 + m * 16 + li;
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                v[r] = fmaxf(acc[m][nb][r] + bv[r], 0.f);
+                const float d = px < HW ? v[r] - sh[r] : 0.f;
+                s1[r] += d;
+                s2[r] = __builtin_fmaf(d, d, s2[r]);
+            }
+            if (px < HW && cb < ld_a)
+                *reinterpret_cast<float4*>(a + ((long long)b * HW + px) * ld_a + cb) = make_float4(v[0], v[1], v[2], v[3]);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            s1[r] = hd_row16_sum(s1[r]);
+            s2[r] = hd_row16_sum(s2[r]);
+            if (li == 0) wsum[wave][cb + r] = make_float2(s1[r], s2[r]);
+        }
+    }
+    __syncthreads();
+    if (tid < C) {
+        float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+        for (int wv = 0; wv < 4; ++wv) { t1 += wsum[wv][tid].x; t2 += wsum[wv][tid].y; }
+        *reinterpret_cast<float2*>(stats + (((long long)b * tiles + blockIdx.x) * C + tid) * 2) = make_float2(t1, t2);
+    }
+}
+
+__device__ __forceinline__ float grp8_max(float v) {
+    v = fmaxf(v, __shfl_xor(v, 1, 64));
+    v = fmaxf(v, __shfl_xor(v, 2, 64));
+    return fmaxf(v, __shfl_xor(v, 4, 64));
+}
+__device__ __forceinline__ float grp8_sum(float v) {
+    v += __shfl_xor(v, 1, 64);
+    v += __shfl_xor(v, 2, 64);
+    return v + __shfl_xor(v, 4, 64);
+}
+
+// grid (chunks per sample, B), 256 lanes: a wave takes eight cells at a time, eight lanes to a cell, four classes to
+// a lane (C <= 32); the max, the sum of exponentials and the label's logit are reductions over the cell's eight lanes.
+// labels == nullptr: inference (no CE, no counts).
+__global__ __launch_bounds__(HNM_T) void head_norm_ce_kernel(const float* __restrict__ a, int ld_a, const float* __restrict__ stats,
+                                                             int tiles, CellMap cm, int C, float eps, const float* __restrict__ bias,
+                                                             float* __restrict__ logits, int ld_l, float* __restrict__ probs,
+                                                             const void* __restrict__ labels, int label_bytes,
+                                                             float* __restrict__ ce, int32_t* __restrict__ bad_labels, void* ws_,
+                                                             int chunks) {
+    __shared__ float tab[2][32];
+    __shared__ int hist[HNM_B0];
+    __shared__ int shi[4];
+    __shared__ float shf[4];
+    const int tid = threadIdx.x;
+    const int b = blockIdx.y, chunk = b * gridDim.x + blockIdx.x;
+    if (tid < 32) {
+        float mean = 0.f, inv = 0.f;
+        if (tid < C) {
+            float s = 0.f, ss = 0.f;
+            for (int t = 0; t < tiles; ++t) {      // slot order, as norm.hip's fold
+                const float2 v = *reinterpret_cast<const float2*>(stats + (((long long)b * tiles + t) * C + tid) * 2);
+                s += v.x;
+                ss += v.y;
+            }
+            norm_mean_inv(s, ss, 1.f / (float)cm.HW, norm_shift(bias, 1, tid), eps, mean, inv);
+        }
+        tab[0][tid] = mean;
+        tab[1][tid] = inv;
+    }
+    if (labels) for (int i = tid; i < HNM_B0; i += HNM_T) hist[i] = 0;
+    __syncthreads();
+    const int q = tid & 7, g = tid >> 3;
+    float mean[4], inv[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { mean[e] = tab[0][q * 4 + e]; inv[e] = tab[1][q * 4 + e]; }
+    int nfg = 0, nbg = 0;
+    float sum_fg = 0.f;
+    for (int pass = 0; pass < HNM_CHUNK / 32; ++pass) {
+        bool in;
+        const long long i = chunk_cell(cm, chunk, pass * 32 + g, in);
+        float y[4] = {0.f, 0.f, 0.f, 0.f};
+        if (in && q * 4 < ld_a) {
+            const float4 v = *reinterpret_cast<const float4*>(a + i * ld_a + q * 4);
+            y[0] = (v.x - mean[0]) * inv[0]; y[1] = (v.y - mean[1]) * inv[1];
+            y[2] = (v.z - mean[2]) * inv[2]; y[3] = (v.w - mean[3]) * inv[3];
+        }
+        if (in && q * 4 < ld_l) *reinterpret_cast<float4*>(logits + i * ld_l + q * 4) = make_float4(y[0], y[1], y[2], y[3]);
+        float mx = -3.0e38f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) if (q * 4 + e < C) mx = fmaxf(mx, y[e]);
+        mx = grp8_max(mx);
+        float ex[4], sum = 0.f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { ex[e] = q * 4 + e < C ? expf(y[e] - mx) : 0.f; sum += ex[e]; }
+        sum = grp8_sum(sum);
+        if (in && probs) {
+            const float r = 1.f / sum;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) if (q * 4 + e < C) probs[i * C + q * 4 + e] = ex[e] * r;
+        }
+        if (!labels) continue;
+        const int lab = in ? label_at(labels, label_bytes, i) : 0;
+        float yl = 0.f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) if (q * 4 + e == lab) yl = y[e];
+        yl = grp8_sum(yl);
+        if (in && q == 0) {
+            float loss;
+            if (lab >= 0 && lab < C) loss = logf(sum) - (yl - mx);
+            else { loss = nanf(""); atomicAdd(bad_labels, 1); }
+            ce[i] = loss;
+            if (lab != 0) { ++nfg; sum_fg += loss; }
+            else { ++nbg; atomicAdd(&hist[sortable(loss) >> 21], 1); }
+        }
+    }
+    if (!labels) return;
+    const HnmWs ws = hnm_ws(ws_, chunks);
+    nfg = block_sum_i256(nfg, shi);
+    nbg = block_sum_i256(nbg, shi);
+    sum_fg = block_sum_f256(sum_fg, shf);
+    if (tid == 0) {
+        if (nfg) atomicAdd(&ws.counts[0], nfg);
+        if (nbg) atomicAdd(&ws.counts[1], nbg);
+        ws.sum_fg[chunk] = sum_fg;
+    }
+    for (int i = tid; i < HNM_B0; i += HNM_T)
+        if (hist[i]) atomicAdd(&ws.hist0[i], hist[i]);
+}
+
+// dz of the logits layer: dy = S * w * (probs - onehot) (cutie_softmax_ce_bwd), then the instance norm's and the
+// ReLU's gradient, dz = [a > 0] * inv * (dy - mean(dy) - y * mean(dy * y)) (cutie_in_bwd_apply's operations), in the
+// activation dtype for the data gradient and the weight gradient that follow; chunk (b, cs) STORES row b*cps + cs of
+// the bias-gradient partials.  Workgroup (0, 0) also writes the loss.  grid (chunks per sample, B).
+template <typename TZ>
+__global__ __launch_bounds__(HNM_T) void head_bwd_kernel(const float* __restrict__ a, int ld_a, const float* __restrict__ stats, int tiles,
+                                                         const float* __restrict__ logits, int ld_l, const float* __restrict__ probs,
+                                                         const void* __restrict__ labels, int label_bytes,
+                                                         const float* __restrict__ weight, const float* __restrict__ red,
+                                                         CellMap cm, int C, float eps, const float* __restrict__ bias,
+                                                         const float* __restrict__ loss_scale, TZ* __restrict__ dz, int ld_dz,
+                                                         float* __restrict__ dbias, void* ws_, int chunks, int ratio,
+                                                         float* __restrict__ loss_out) {
+    __shared__ float tab[3][32];          // inv, mean(dy), mean(dy * y)
+    __shared__ float racc[32][32];
+    const int tid = threadIdx.x;
+    const int b = blockIdx.y, chunk = b * gridDim.x + blockIdx.x;
+    if (chunk == 0 && tid == 0) hnm_final(hnm_ws(ws_, chunks), chunks, ratio, loss_out);
+    if (tid < 32) {
+        float inv = 0.f, m1 = 0.f, m2 = 0.f;
+        if (tid < C) {
+            float s = 0.f, ss = 0.f, mean;
+            for (int t = 0; t < tiles; ++t) {
+                const float2 v = *reinterpret_cast<const float2*>(stats + (((long long)b * tiles + t) * C + tid) * 2);
+                s += v.x;
+                ss += v.y;
+            }
+            const float inv_n = 1.f / (float)cm.HW;
+            norm_mean_inv(s, ss, inv_n, norm_shift(bias, 1, tid), eps, mean, inv);
+            for (int t = 0; t < cm.cps; ++t) {
+                const float2 v = *reinterpret_cast<const float2*>(red + (((long long)b * cm.cps + t) * C + tid) * 2);
+                m1 += v.x;
+                m2 += v.y;
+            }
+            m1 *= inv_n;
+            m2 *= inv_n;
+        }
+        tab[0][tid] = inv;
+        tab[1][tid] = m1;
+        tab[2][tid] = m2;
+    }
+    __syncthreads();
+    const int q = tid & 7, g = tid >> 3;
+    const float S = loss_scale ? loss_scale[0] : 1.f;
+    float inv[4], m1[4], m2[4], sb[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { inv[e] = tab[0][q * 4 + e]; m1[e] = tab[1][q * 4 + e]; m2[e] = tab[2][q * 4 + e]; }
+    if (q * 4 < ld_a) {
+        for (int pass = 0; pass < HNM_CHUNK / 32; ++pass) {
+            bool in;
+            const long long i = chunk_cell(cm, chunk, pass * 32 + g, in);
+            if (!in) continue;
+            const float4 av = *reinterpret_cast<const float4*>(a + i * ld_a + q * 4);
+            const float4 yv = *reinterpret_cast<const float4*>(logits + i * ld_l + q * 4);
+            const float ae[4] = {av.x, av.y, av.z, av.w}, ye[4] = {yv.x, yv.y, yv.z, yv.w};
+            const float w = weight[i];
+            const int lab = w != 0.f ? label_at(labels, label_bytes, i) : -1;
+            TZ o[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int c = q * 4 + e;
+                float dy = 0.f;
+                if (w != 0.f && c < C) dy = S * w * (probs[i * C + c] - (lab == c ? 1.f : 0.f));
+                float d = inv[e] * __builtin_fmaf(-ye[e], m2[e], dy - m1[e]);
+                if (!(ae[e] > 0.f) || c >= C) d = 0.f;
+                sb[e] += d;
+                store_from_f32(&o[e], d);
+            }
+            if (q * 4 < ld_dz) {
+                if constexpr (sizeof(TZ) == 2) *reinterpret_cast<uint2*>(dz + i * ld_dz + q * 4) = *reinterpret_cast<const uint2*>(o);
+                else *reinterpret_cast<float4*>(dz + i * ld_dz + q * 4) = *reinterpret_cast<const float4*>(o);
+            }
+        }
+    }
+    if (!dbias) return;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) racc[g][q * 4 + e] = sb[e];
+    __syncthreads();
+    if (tid < C) {
+        float t = 0.f;
+#pragma unroll 8
+        for (int r = 0; r < 32; ++r) t += racc[r][tid];
+        dbias[(long long)chunk * C + tid] = t;
+    }
+}
 }  // namespace
 
 extern "C" size_t cutie_ghm_state_bytes(int bins) {
@@ -505,11 +882,13 @@ static int hnm_launch(const float* ce, const int32_t* labels, int64_t n_cells, i
     const int chunks = (int)hnm_chunks(n_cells);
     CUTIE_CHECK_HIP(hipMemsetAsync(ws, 0, (size_t)(HNM_INT_HEAD + 3 * chunks) * 4, stream));
     const dim3 g(chunks), t(HNM_T);
-    hipLaunchKernelGGL(hnm_count_kernel, g, t, 0, stream, ce, labels, n_cells, chunks, ws);
-    hipLaunchKernelGGL(hnm_hist_kernel<1>, g, t, 0, stream, ce, labels, n_cells, chunks, ratio, ws);
-    hipLaunchKernelGGL(hnm_hist_kernel<2>, g, t, 0, stream, ce, labels, n_cells, chunks, ratio, ws);
-    hipLaunchKernelGGL(hnm_tie_kernel, g, t, 0, stream, ce, labels, n_cells, chunks, ratio, ws);
-    hipLaunchKernelGGL(hnm_weight_kernel, g, t, 0, stream, ce, labels, n_cells, chunks, ratio, ws, weight);
+    const CellMap cm = {(long long)n_cells, chunks};      // one "sample" of n_cells cells
+    const HeadRed none = {nullptr, nullptr, 0, 0, nullptr, nullptr};
+    hipLaunchKernelGGL(hnm_count_kernel, g, t, 0, stream, ce, (const void*)labels, 4, cm, chunks, ws);
+    hipLaunchKernelGGL(hnm_hist_kernel<1>, g, t, 0, stream, ce, (const void*)labels, 4, cm, chunks, ratio, ws);
+    hipLaunchKernelGGL(hnm_hist_kernel<2>, g, t, 0, stream, ce, (const void*)labels, 4, cm, chunks, ratio, ws);
+    hipLaunchKernelGGL(hnm_tie_kernel, g, t, 0, stream, ce, (const void*)labels, 4, cm, chunks, ratio, ws);
+    hipLaunchKernelGGL(hnm_weight_kernel, g, t, 0, stream, ce, (const void*)labels, 4, cm, chunks, ratio, ws, weight, none);
     hipLaunchKernelGGL(hnm_final_kernel, dim3(1), dim3(64), 0, stream, chunks, ratio, ws, loss_out);
     CUTIE_CHECK_LAUNCH();
     return CUTIE_OK;
@@ -575,6 +954,98 @@ extern "C" int cutie_hnm_weights_static(const float* ce, const int32_t* labels, 
     if (int e = hnm_scratch_for_current_device(&ws)) return e;
     // the array keeps the last call's histograms: hnm_launch clears what this call's size uses before anything reads it
     return hnm_launch(ce, labels, n_cells, ratio, weight, loss_out, ws, stream);
+}
+
+// ---------------------------------------------------------------------------------------------
+extern "C" int cutie_head_tiles(int HW) { return HW < 1 ? 1 : (HW + HEAD_TILE - 1) / HEAD_TILE; }
+extern "C" int cutie_head_chunks(int HW) { return HW < 1 ? 1 : (HW + HNM_CHUNK - 1) / HNM_CHUNK; }
+extern "C" size_t cutie_head_workspace_bytes(int B, int HW) {
+    return (size_t)(HNM_INT_HEAD + 3 * (int64_t)(B < 1 ? 1 : B) * cutie_head_chunks(HW)) * 4 + 64;
+}
+
+static int head_check(const char* name, int B, int HW, int C, int ld_a, int ld_l, const void* a, const void* logits) {
+    CUTIE_CHECK_ARG(B >= 0 && HW >= 1 && C >= 1 && C <= 32, "%s: B=%d HW=%d C=%d (C <= 32)", name, B, HW, C);
+    CUTIE_CHECK_ARG(ld_a >= C && ld_a % 4 == 0 && ld_l >= C && ld_l % 4 == 0 && cutie::aligned16(a) && cutie::aligned16(logits),
+                    "%s: a / logits need 16-byte aligned rows (ld %d / %d)", name, ld_a, ld_l);
+    CUTIE_CHECK_ARG((int64_t)B * HW < (1ll << 31) - HNM_CHUNK, "%s: too many cells", name);
+    return CUTIE_OK;
+}
+
+extern "C" int cutie_head_fwd(const void* x, int ld_x, int dtype, int B, int HW, int cin, const float* w_hwio,
+                              const float* bias, int C, float eps, float* a, int ld_a, float* stats, int stats_tiles,
+                              float* logits, int ld_logits, float* probs, const void* labels, int label_bytes, float* ce,
+                              int32_t* bad_labels, void* workspace, size_t workspace_bytes, cutie_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (int e = head_check("head_fwd", B, HW, C, ld_a, ld_logits, a, logits)) return e;
+    CUTIE_CHECK_ARG(dtype == CUTIE_BF16 || dtype == CUTIE_F16, "head_fwd: 16-bit activations only (dtype %d)", dtype);
+    CUTIE_CHECK_ARG(cin >= 32 && cin % 32 == 0 && cin <= 32 * HEAD_MAX_KK && ld_x >= cin && (ld_x * 2) % 16 == 0 && cutie::aligned16(x),
+                    "head_fwd: cin=%d (multiple of 32, <= %d), ld_x=%d", cin, 32 * HEAD_MAX_KK, ld_x);
+    if (B == 0) return CUTIE_OK;
+    CUTIE_CHECK_ARG(x && w_hwio && bias && a && stats && logits, "head_fwd: null pointer");
+    CUTIE_CHECK_ARG(stats_tiles >= cutie_head_tiles(HW), "head_fwd: stats_tiles=%d < cutie_head_tiles(%d)", stats_tiles, HW);
+    CUTIE_CHECK_ARG(!labels || ((label_bytes == 1 || label_bytes == 4) && ce && bad_labels), "head_fwd: labels need ce and bad_labels");
+    const int tiles = cutie_head_tiles(HW), cps = cutie_head_chunks(HW);
+    void* ws = nullptr;
+    if (labels) {
+        const size_t need = cutie_head_workspace_bytes(B, HW);
+        if (!workspace || workspace_bytes < need) {
+            cutie::set_error("head_fwd: workspace %zu < %zu", workspace_bytes, need);
+            return CUTIE_E_WORKSPACE;
+        }
+        ws = (void*)(((uintptr_t)workspace + 15) & ~(uintptr_t)15);
+        CUTIE_CHECK_HIP(hipMemsetAsync(ws, 0, (size_t)(HNM_INT_HEAD + 3 * (int64_t)B * cps) * 4, stream));
+    }
+    if (dtype == CUTIE_BF16) {
+        hipLaunchKernelGGL(head_conv_kernel<CUTIE_BF16>, dim3(tiles, B), dim3(256), 0, stream, (const bf16_t*)x, ld_x, HW, cin,
+                           w_hwio, bias, C, a, ld_a, stats, stats_tiles);
+    } else {
+        hipLaunchKernelGGL(head_conv_kernel<CUTIE_F16>, dim3(tiles, B), dim3(256), 0, stream, (const f16_t*)x, ld_x, HW, cin,
+                           w_hwio, bias, C, a, ld_a, stats, stats_tiles);
+    }
+    CUTIE_CHECK_LAUNCH();
+    const CellMap cm = {(long long)HW, cps};
+    hipLaunchKernelGGL(head_norm_ce_kernel, dim3(cps, B), dim3(HNM_T), 0, stream, (const float*)a, ld_a, (const float*)stats,
+                       stats_tiles, cm, C, eps, bias, logits, ld_logits, probs, labels, label_bytes, ce, bad_labels, ws, B * cps);
+    CUTIE_CHECK_LAUNCH();
+    return CUTIE_OK;
+}
+
+extern "C" int cutie_head_bwd(const float* a, int ld_a, const float* stats, int stats_tiles, const float* logits,
+                              int ld_logits, const float* probs, const void* labels, int label_bytes, const float* ce,
+                              int B, int HW, int C, float eps, const float* bias, int ratio, const float* loss_scale,
+                              float* weight, float* red, float* loss_out, void* dz, int ld_dz, int dz_dtype,
+                              float* dbias_part, void* workspace, size_t workspace_bytes, cutie_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (int e = head_check("head_bwd", B, HW, C, ld_a, ld_logits, a, logits)) return e;
+    CUTIE_CHECK_ARG(ratio >= 0 && (label_bytes == 1 || label_bytes == 4), "head_bwd: ratio=%d label_bytes=%d", ratio, label_bytes);
+    if (B == 0) return CUTIE_OK;
+    CUTIE_CHECK_ARG(a && stats && logits && probs && labels && ce && bias && weight && red && loss_out && dz,
+                    "head_bwd: null pointer");
+    CUTIE_CHECK_ARG(stats_tiles >= cutie_head_tiles(HW), "head_bwd: stats_tiles=%d", stats_tiles);
+    const int es = dz_dtype == CUTIE_F32 ? 4 : 2;
+    CUTIE_CHECK_ARG(ld_dz >= C && (ld_dz * es) % (4 * es) == 0 && (reinterpret_cast<uintptr_t>(dz) % (4 * es)) == 0,
+                    "head_bwd: dz rows must hold whole groups of four classes (ld_dz=%d)", ld_dz);
+    const size_t need = cutie_head_workspace_bytes(B, HW);
+    if (!workspace || workspace_bytes < need) {
+        cutie::set_error("head_bwd: workspace %zu < %zu", workspace_bytes, need);
+        return CUTIE_E_WORKSPACE;
+    }
+    void* ws = (void*)(((uintptr_t)workspace + 15) & ~(uintptr_t)15);
+    const int cps = cutie_head_chunks(HW), chunks = B * cps;
+    const CellMap cm = {(long long)HW, cps};
+    const dim3 g(chunks), t(HNM_T);
+    const HeadRed hr = {probs, logits, ld_logits, C, loss_scale, red};
+    hipLaunchKernelGGL(hnm_hist_kernel<1>, g, t, 0, stream, ce, labels, label_bytes, cm, chunks, ratio, ws);
+    hipLaunchKernelGGL(hnm_hist_kernel<2>, g, t, 0, stream, ce, labels, label_bytes, cm, chunks, ratio, ws);
+    hipLaunchKernelGGL(hnm_tie_kernel, g, t, 0, stream, ce, labels, label_bytes, cm, chunks, ratio, ws);
+    hipLaunchKernelGGL(hnm_weight_kernel, g, t, 0, stream, ce, labels, label_bytes, cm, chunks, ratio, ws, weight, hr);
+    CUTIE_CHECK_LAUNCH();
+    CUTIE_DISPATCH_DTYPE(dz_dtype, DT,
+        hipLaunchKernelGGL(head_bwd_kernel<typename elem<DT>::type>, dim3(cps, B), t, 0, stream, a, ld_a, stats, stats_tiles,
+                           logits, ld_logits, probs, labels, label_bytes, (const float*)weight, (const float*)red, cm, C, eps,
+                           bias, loss_scale, (typename elem<DT>::type*)dz, ld_dz, dbias_part, ws, chunks, ratio, loss_out));
+    CUTIE_CHECK_LAUNCH();
+    return CUTIE_OK;
 }
 
 extern "C" int cutie_softmax_ce_bwd(const float* probs, const int32_t* labels, const float* weight, int64_t n_cells,

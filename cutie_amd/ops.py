@@ -205,11 +205,12 @@ def conv_sync_bytes(B, red_tiles, n_out):
     return capi.lib().cutie_conv_sync_bytes(int(B), int(red_tiles), int(n_out))
 
 
-def conv_in_fwd(segs, a, y, n_out, bias, relu, stats, sync=None, eps=IN_EPS):
+def conv_in_fwd(segs, a, y, n_out, bias, relu, stats, sync=None, eps=IN_EPS, late=None):
     """conv + bias + activation + instance norm as one call (cutie_conv_in_fwd): a = scratch view for the pre-norm
     activation, y = output view, stats as conv_fwd.  With `sync` (int32 tensor of conv_sync_bytes(B, T, n_out) bytes, zeroed
     once, dedicated to this layer and shape) the launch may store y directly and leave `a` unwritten; returns True when it
-    did - the backward functions then take y in place of a with from_y=True."""
+    did - the backward functions then take y in place of a with from_y=True.  late: the caller's step-wide int32 [1]
+    counter of waits that ran out (see conv_dgrad_in_bwd)."""
     B = y.shape[0]
     arr, dt = _seg_array(segs, y, n_out, "conv_in_fwd")
     if dt_of(a) != dt or dt_of(y) != dt:
@@ -217,18 +218,20 @@ def conv_in_fwd(segs, a, y, n_out, bias, relu, stats, sync=None, eps=IN_EPS):
     fused = ctypes.c_int(0)
     call("cutie_conv_in_fwd", arr, len(segs), B, y.shape[1], y.shape[2], n_out, ptr(a), ld_of(a), ptr(y), ld_of(y), ptr(bias),
          ACTIVATION_CODE[relu], ptr(stats), _tiles(stats, B, n_out, True), eps, ptr(sync),
-         sync.numel() * sync.element_size() if sync is not None else 0, ctypes.byref(fused), dt, stream())
+         sync.numel() * sync.element_size() if sync is not None else 0, ptr(late), ctypes.byref(fused), dt, stream())
     return bool(fused.value)
 
 
 def conv_dgrad_in_bwd(segs, dy, n_out, a, stats, red, dz, dbias_part=None, relu=True, sync=None, eps=IN_EPS, bias=None,
-                      from_y=False):
+                      from_y=False, late=None):
     """Data gradient of an instance-normalised layer and the gradient of its norm + activation in one call
     (cutie_conv_dgrad_in_bwd): segs as conv_fwd (flip=True), dy = scratch view [B,H,W,>=n_out], a / stats = the layer's
     forward activation and moments, red = f32 [B,T,n_out,2] zeroed once, dz = output view, dbias_part f32 [B*T', n_out],
     sync = int32 tensor of conv_sync_bytes(B, T, n_out) bytes zeroed once and dedicated to this layer and shape
     (None: two-call form).  sync[0] counts tiles whose bounded wait ran out.  bias: the layer's bias - with `relu` the
-    shift its moments are kept about (None when they were produced without one)."""
+    shift its moments are kept about (None when they were produced without one).  late: int32 [1] device counter of the
+    caller's, bumped together with sync[0]: one word for a whole step, which the optimizer entry points take as
+    `invalid` and skip the update on."""
     B = dy.shape[0]
     arr, dt = _seg_array(segs, dy, n_out, "conv_dgrad_in_bwd")
     if dt_of(dy) != dt or dt_of(a) != dt or dt_of(dz) != dt:
@@ -236,7 +239,7 @@ def conv_dgrad_in_bwd(segs, dy, n_out, a, stats, red, dz, dbias_part=None, relu=
     call("cutie_conv_dgrad_in_bwd", arr, len(segs), B, dy.shape[1], dy.shape[2], n_out, ptr(dy), ld_of(dy), ptr(a), ld_of(a),
          ptr(stats), _tiles(stats, B, n_out, True), eps, ptr(red), _tiles(red, B, n_out, True), _act(relu, from_y),
          ptr(bias), ptr(dz), ld_of(dz), ptr(dbias_part), _tiles(dbias_part, B, n_out, False), ptr(sync),
-         sync.numel() * sync.element_size() if sync is not None else 0, dt, stream())
+         sync.numel() * sync.element_size() if sync is not None else 0, ptr(late), dt, stream())
     return dz
 
 
@@ -395,6 +398,59 @@ def softmax_ce_bwd(probs, labels, weight, C, dlogits, loss_scale=None, elem_weig
          ld_of(dlogits), dt_of(dlogits), ptr(loss_scale), ptr(elem_weight), stream())
 
 
+def _label_bytes(labels):
+    if labels.dtype == torch.int8:
+        return 1
+    if labels.dtype == torch.int32:
+        return 4
+    raise capi.CutieError("labels must be int8 or int32, not %s" % labels.dtype)
+
+
+def head_tiles(HW):
+    return capi.lib().cutie_head_tiles(int(HW))
+
+
+def head_chunks(HW):
+    return capi.lib().cutie_head_chunks(int(HW))
+
+
+def head_workspace_bytes(B, HW):
+    return capi.lib().cutie_head_workspace_bytes(int(B), int(HW))
+
+
+def head_fwd(x, cin, w_hwio, bias, C, a, stats, logits, probs=None, labels=None, ce=None, bad=None, workspace=None, eps=IN_EPS):
+    """the logits layer + instance norm + softmax (+ CE and level 0 of the hard-negative select with labels) - cutie_head_fwd.
+    x [B,H,W,>=cin] 16-bit view; w_hwio f32 [1,1,cin,C] contiguous; a / logits f32 [B,H,W,ld]; stats f32 [B,T,C,2];
+    probs f32 [B*H*W, C] contiguous; labels int8 / int32 [B,H,W] contiguous"""
+    B, HW = x.shape[0], x.shape[1] * x.shape[2]
+    if tuple(w_hwio.shape[-2:]) != (cin, C) or not w_hwio.is_contiguous() or w_hwio.dtype != torch.float32:
+        raise capi.CutieError("head_fwd: weights must be contiguous f32 [1,1,%d,%d], got %s" % (cin, C, tuple(w_hwio.shape)))
+    if probs is not None and (not probs.is_contiguous() or probs.numel() != B * HW * C):
+        raise capi.CutieError("head_fwd: probs must be contiguous [B*H*W, C]")
+    if labels is not None and (not labels.is_contiguous() or labels.numel() != B * HW):
+        raise capi.CutieError("head_fwd: labels must be contiguous [B,H,W]")
+    call("cutie_head_fwd", ptr(x), ld_of(x), dt_of(x), B, HW, cin, ptr(w_hwio), ptr(bias), C, eps, ptr(a), ld_of(a),
+         ptr(stats), _tiles(stats, B, C, True), ptr(logits), ld_of(logits), ptr(probs), ptr(labels),
+         _label_bytes(labels) if labels is not None else 4, ptr(ce), ptr(bad), ptr(workspace),
+         workspace.numel() * workspace.element_size() if workspace is not None else 0, stream(x.device))
+
+
+def head_bwd(a, stats, logits, probs, labels, ce, C, bias, ratio, weight, red, loss_out, dz, dbias_part, workspace,
+             loss_scale=None, eps=IN_EPS):
+    """hard-negative select + d(loss)/d(logits) + the logits layer's norm / ReLU gradient - cutie_head_bwd; must follow
+    head_fwd (same workspace).  red f32 [B, head_chunks(HW), C, 2]; dz [B,H,W,>=C] view; dbias_part f32 [B*chunks, C]"""
+    B, HW = a.shape[0], a.shape[1] * a.shape[2]
+    cps = head_chunks(HW)
+    if red.numel() != B * cps * C * 2 or not red.is_contiguous() or red.dtype != torch.float32:
+        raise capi.CutieError("head_bwd: red must be contiguous f32 [B, %d, C, 2]" % cps)
+    if dbias_part is not None and (dbias_part.numel() < B * cps * C or not dbias_part.is_contiguous()):
+        raise capi.CutieError("head_bwd: dbias_part needs %d rows of C" % (B * cps))
+    call("cutie_head_bwd", ptr(a), ld_of(a), ptr(stats), _tiles(stats, B, C, True), ptr(logits), ld_of(logits), ptr(probs),
+         ptr(labels), _label_bytes(labels), ptr(ce), B, HW, C, eps, ptr(bias), int(ratio), ptr(loss_scale), ptr(weight),
+         ptr(red), ptr(loss_out), ptr(dz), ld_of(dz), dt_of(dz), ptr(dbias_part), ptr(workspace),
+         workspace.numel() * workspace.element_size(), stream(a.device))
+
+
 def ghm_state(bins, device):
     """zeroed device state for ghm_weights (acc_sum carries over between steps)"""
     n = capi.lib().cutie_ghm_state_bytes(int(bins))
@@ -421,22 +477,61 @@ def sumsq(x, out, scratch, loss_scale=None):
 
 
 def loss_scale_state(scale, device):
-    """device array {S, 1/S, good steps in a row, steps skipped} (include/cutie_hip.h, K12)"""
-    state = torch.zeros(4, dtype=torch.float32, device=device)
+    """device array {S, 1/S, good steps in a row, steps skipped, of them invalid, ...} (include/cutie_hip.h, K12)"""
+    state = torch.zeros(capi.LOSS_SCALE_STATE, dtype=torch.float32, device=device)
     call("cutie_loss_scale_init", ptr(state), float(scale), stream())
     return state
 
 
-def loss_scale_update(state, gnorm_sq, backoff=0.5, growth=2.0, interval=1000, min_scale=1.0, max_scale=65536.0):
+def loss_scale_update(state, gnorm_sq, backoff=0.5, growth=2.0, interval=1000, min_scale=1.0, max_scale=65536.0,
+                      invalid=None):
     call("cutie_loss_scale_update", ptr(state), ptr(gnorm_sq), float(backoff), float(growth), int(interval),
-         float(min_scale), float(max_scale), stream())
+         float(min_scale), float(max_scale), ptr(invalid), stream())
 
 
-def adam_step(p, g, m, v, lr_t, beta1, beta2, eps, gnorm_sq, clip, grad_scale=1.0, t=0, loss_scale=None):
+def adam_step(p, g, m, v, lr_t, beta1, beta2, eps, gnorm_sq, clip, grad_scale=1.0, t=0, loss_scale=None, invalid=None):
     """t, loss_scale: the caller's step count behind lr_t and the loss-scale state - with both, the kernel re-bases the
-    bias correction to the steps the device did not skip (an f16 overflow skips a step without the host knowing)"""
+    bias correction to the steps the device did not skip (an f16 overflow skips a step without the host knowing).
+    invalid: int32 [1] device counter; non-zero skips the step (conv_dgrad_in_bwd's `late`)."""
     call("cutie_adam_step", ptr(p), ptr(g), ptr(m), ptr(v), p.numel(), float(lr_t), float(beta1), float(beta2),
-         float(eps), ptr(gnorm_sq), float(clip), float(grad_scale), int(t), ptr(loss_scale), stream())
+         float(eps), ptr(gnorm_sq), float(clip), float(grad_scale), int(t), ptr(loss_scale), ptr(invalid), stream())
+
+
+def opt_layers(entries):
+    """entries: (w_hwio view INTO the flat parameter buffer, w_fwd or None, w_dgrad or None) per conv layer, in the order
+    of the flat buffer -> the host descriptor array cutie_opt_step walks (kept by the caller)"""
+    if len(entries) > capi.MAX_BATCH:
+        raise capi.CutieError("opt_layers: %d layers (max %d)" % (len(entries), capi.MAX_BATCH))
+    arr = (capi.PackDesc * max(1, len(entries)))()
+    for i, (w, wf, wd) in enumerate(entries):
+        kh, kw, cin, cout = w.shape
+        if not w.is_contiguous() or w.dtype != torch.float32:
+            raise capi.CutieError("opt_layers: weights must be contiguous f32 HWIO views")
+        arr[i].w_hwio, arr[i].w_fwd, arr[i].w_dgrad = ptr(w), ptr(wf), ptr(wd)
+        arr[i].taps, arr[i].cin, arr[i].cout = kh * kw, cin, cout
+        arr[i].cin_pad = wf.shape[2] if wf is not None else 0
+        arr[i].cout_pad = wd.shape[2] if wd is not None else 0
+    return arr, len(entries)
+
+
+def opt_norm(w, g, n_l2, n_dense, wd, partials, rows=None, loss_scale=None):
+    """pass 1 of the optimizer tail (cutie_opt_norm): partial sums of (g/S + wd*w)^2 and w^2; rows = the embedding's
+    per-cell gradient rows (still scaled), contiguous"""
+    if partials.numel() < capi.OPT_SCRATCH or partials.dtype != torch.float32:
+        raise capi.CutieError("opt_norm: partials needs %d f32 elements" % capi.OPT_SCRATCH)
+    call("cutie_opt_norm", ptr(w), ptr(g), int(n_l2), int(n_dense), float(wd), ptr(rows),
+         rows.numel() if rows is not None else 0, dt_of(rows) if rows is not None else F32, ptr(loss_scale), ptr(partials),
+         stream(w.device))
+
+
+def opt_step(p, g, m, v, n_l2, wd, reg_scale, layers, dt, lr_t, beta1, beta2, eps, clip, grad_scale, t, partials,
+             extra_sq=None, loss_scale=None, invalid=None, gnorm_sq_out=None, reg_out=None, zero_from=-1):
+    """pass 2 (cutie_opt_step): clip + Adam over the flat buffers, the conv kernels in tiles that also write the packed
+    16-bit operands; layers = opt_layers(...)"""
+    arr, n = layers
+    call("cutie_opt_step", ptr(p), ptr(g), ptr(m), ptr(v), p.numel(), int(n_l2), float(wd), float(reg_scale), arr, n, dt,
+         float(lr_t), float(beta1), float(beta2), float(eps), float(clip), float(grad_scale), int(t), ptr(partials),
+         ptr(extra_sq), ptr(loss_scale), ptr(invalid), ptr(gnorm_sq_out), ptr(reg_out), int(zero_from), stream(p.device))
 
 
 def batch_scatter_add(dout, idx, dfeat):

@@ -53,7 +53,10 @@ class Engine(object):
         if loss_scale is None and self.dt == F16:
             loss_scale = 4096.0
         with torch.cuda.device(self.dev):
-            self.loss_scale = ops.loss_scale_state(loss_scale, self.dev) if loss_scale else None
+            # optimizer state on the device {S, 1/S, good steps, steps skipped, of them invalid, ...}: every element type has
+            # one (the skipped-step count re-bases Adam's bias correction); only f16 scales its backward pass by S
+            self.opt_state = ops.loss_scale_state(loss_scale if loss_scale else 1.0, self.dev)
+            self.loss_scale = self.opt_state if loss_scale else None
         # Optional: backward on two HIP streams - the weight gradients (MFMA-bound, needed only by the optimizer
         # and the all-reduce) beside the data-gradient / norm-backward chain (whose norm passes are HBM-bound).
         # Off by default: measured on the MI355X (tools/gpu_overlap.sh, alternating runs on one box) it is 0.45 %
@@ -214,10 +217,21 @@ class Engine(object):
         pooled = [n.inputs[0].channels for n in nodes if n.op == "global_pool"]
         P.pool_scratch = (torch.zeros(B * capi.POOL_TILES * max(pooled) * 2, dtype=torch.float32, device=dev)
                           if pooled else None)
-        P.counters = torch.zeros(3, dtype=torch.int32, device=dev)     # one fill per forward clears all
+        P.counters = torch.zeros(4, dtype=torch.int32, device=dev)     # one fill per forward clears all
         P.oob, P.bad, P.ps_oob = P.counters[0:1], P.counters[1:2], P.counters[2:3]
+        # conv tiles that gave up waiting for their sample's other tiles in any launch of the step (forward or backward):
+        # the optimizer skips the update on the device when it is non-zero (cutie_opt_step `invalid`)
+        P.late = P.counters[3:4]
         N = B * H * W
         P.N = N
+        # the logits head (1x1 conv + norm + softmax + CE + hard-negative select) as its own few launches: cutie_head_*
+        P.head = self._head_node()
+        if P.head is not None:
+            Cp = _pad(self.C, 4)
+            P.head_a = torch.zeros((B, H, W, Cp), dtype=torch.float32, device=dev)
+            P.head_stats = torch.zeros((B, ops.head_tiles(H * W), self.C, 2), dtype=torch.float32, device=dev)
+            P.head_red = torch.zeros((B, ops.head_chunks(H * W), self.C, 2), dtype=torch.float32, device=dev)
+            P.head_ws = torch.empty(ops.head_workspace_bytes(B, H * W), dtype=torch.uint8, device=dev)
         P.ce = torch.zeros(N, dtype=torch.float32, device=dev)
         P.probs = torch.zeros((B, H, W, self.C), dtype=torch.float32, device=dev)
         P.weight = torch.zeros(N, dtype=torch.float32, device=dev)
@@ -229,6 +243,28 @@ class Engine(object):
         P.bwd_ready = False
         self._plans[key] = P
         return P
+
+    # CUTIE_HEAD_FUSED=0: the logits layer and the loss on the general kernels (conv, in_stats, in_apply, softmax_ce, hnm, ...)
+    head_fused = os.environ.get("CUTIE_HEAD_FUSED", "1") != "0"
+
+    def _head_node(self):
+        """the logits conv node when cutie_head_fwd / cutie_head_bwd can take it: 16-bit engine, 1x1, ReLU, at most 32 classes,
+        feeding the loss softmax and nothing else; else None (f32 parity path, GHM's sigmoid logits)"""
+        net = self.net
+        lname = getattr(net, "loss_logits_name", None)
+        if not self.head_fused or self.dt == F32 or lname is None or lname not in net.layers:
+            return None
+        n = net.layers[lname]
+        a = n.attrs
+        if n.op != "conv" or a["kh"] != 1 or a["kw"] != 1 or a.get("activation", "relu") != "relu" or n.channels > 32:
+            return None
+        cin_pad = _pad(a["cin"], self.bke)
+        if cin_pad > 256 or n.domain != "grid":
+            return None
+        cons = [c for m in net.nodes for c in [m] if any(i.name == lname for i in m.inputs)]
+        if len(cons) != 1 or cons[0].op != "softmax" or (getattr(net, "loss_spec", None) or {}).get("use_ghm"):
+            return None
+        return n
 
     def _plan_backward(self, P):
         if P.bwd_ready:
@@ -244,7 +280,10 @@ class Engine(object):
             P.red[n.name] = torch.zeros((B, ct, n.channels, 2), dtype=torch.float32, device=dev)
             # the one-launch data gradient (conv_dgrad_in_bwd) leaves one bias-gradient row per conv tile
             fusable = n.name != net.loss_logits_name and self.dt != F32
-            P.dbpart[n.name] = torch.zeros((B * (max(ct, t) if fusable else t), n.channels), dtype=torch.float32, device=dev)
+            rows = max(ct, t) if fusable else t
+            if n is P.head:
+                rows = ops.head_chunks(hs * ws)          # cutie_head_bwd: one row per (sample, 1024-cell chunk)
+            P.dbpart[n.name] = torch.zeros((B * rows, n.channels), dtype=torch.float32, device=dev)
             # tagged granules of that launch's tile rendezvous (word 0: timeouts); zeroed once, then the library's
             P.sync[n.name] = torch.zeros(ops.conv_sync_bytes(B, ct, n.channels) // 4, dtype=torch.int32, device=dev)
         # gradient buffers for every tensor that a conv, the embedding or the sampler produces
@@ -278,31 +317,33 @@ class Engine(object):
         tensor is instance-normalised, so d(mean)/dx is annihilated by the norm's backward
         (DESIGN.md, 'global pool gradient')."""
         segs = []
-
-        def walk(nm, off):
-            for c in P.consumers.get(nm, []):
-                if c.op == "conv":
-                    a = c.attrs
-                    segs.append(dict(x=P.dz[c.name], w=self.w_dg[c.name + "/weights"], cin=_pad(c.channels, self.bke),
-                                     kh=a["kh"], kw=a["kw"], dil=a["rate"], flip=True, n_off=off))
-                elif c.op == "concat":
-                    o = 0
-                    for i in c.inputs:
-                        if i.name == nm:
-                            break
-                        o += i.channels
-                    walk(c.name, off + o)
-                elif c.op == "global_pool":
-                    # dropping this gradient is exact only behind an instance norm (DESIGN.md, 'global pool gradient')
-                    if self.net.layers[nm].op != "conv":
-                        raise NotImplementedError("gradient of global_pool(%s): the pooled tensor is not the output of an "
-                                                  "instance-normalised conv, so the pool's gradient does not vanish" % nm)
-                elif c.op in ("softmax", "positional_sampling"):
-                    pass        # sampler: its scatter-add is added by loss_backward (_sampler_consumers)
-                else:
-                    raise NotImplementedError("gradient through %s (%s)" % (c.name, c.op))
-        walk(name, 0)
+        self._walk_consumers(P, name, 0, segs)
         return segs
+
+    def _walk_consumers(self, P, nm, off, segs):
+        # a method, not a recursive local function: that would be a reference cycle (function <-> its own closure cell)
+        # holding P - and an evicted plan's gigabytes - until the next gc pass
+        for c in P.consumers.get(nm, []):
+            if c.op == "conv":
+                a = c.attrs
+                segs.append(dict(x=P.dz[c.name], w=self.w_dg[c.name + "/weights"], cin=_pad(c.channels, self.bke),
+                                 kh=a["kh"], kw=a["kw"], dil=a["rate"], flip=True, n_off=off))
+            elif c.op == "concat":
+                o = 0
+                for i in c.inputs:
+                    if i.name == nm:
+                        break
+                    o += i.channels
+                self._walk_consumers(P, c.name, off + o, segs)
+            elif c.op == "global_pool":
+                # dropping this gradient is exact only behind an instance norm (DESIGN.md, 'global pool gradient')
+                if self.net.layers[nm].op != "conv":
+                    raise NotImplementedError("gradient of global_pool(%s): the pooled tensor is not the output of an "
+                                              "instance-normalised conv, so the pool's gradient does not vanish" % nm)
+            elif c.op in ("softmax", "positional_sampling"):
+                pass        # sampler: its scatter-add is added by loss_backward (_sampler_consumers)
+            else:
+                raise NotImplementedError("gradient through %s (%s)" % (c.name, c.op))
 
     # CUTIE_WGRAD_BATCH=0: every layer's weight gradient is its own call, right after the layer's dz (round-1 behaviour)
     wgrad_batch = os.environ.get("CUTIE_WGRAD_BATCH", "1") != "0"
@@ -322,6 +363,8 @@ class Engine(object):
         backward pass uses).  From a where it was stored; where only y was, from y's encoding: the a == 0 elements of a
         (sample, channel) plane all hold the plane's smallest value y0 = round16((0 - mean) * inv)."""
         n = self.net.layers[name]
+        if n is P.head:
+            return P.head_a[..., :n.channels] > 0
         if not P.fused.get(name):
             return P.a[name][..., :n.channels] > 0
         y = P.view(name, n.channels).float()
@@ -366,7 +409,8 @@ class Engine(object):
                 ops.conv_dgrad_in_bwd(segs, P.dy[n.name][..., :n.channels], n.channels, av,
                                       P.stats[n.name], P.red[n.name], P.dz[n.name][..., :n.channels],
                                       dbias_part=P.dbpart[n.name], relu=n.attrs.get("activation", "relu"),
-                                      sync=P.sync[n.name], bias=self.params[n.name + "/biases"], from_y=from_y)
+                                      sync=P.sync[n.name], bias=self.params[n.name + "/biases"], from_y=from_y,
+                                      late=P.late)
                 return True
             ops.conv_fwd(segs, P.dy[n.name], n.channels)
         return False
@@ -401,6 +445,18 @@ class Engine(object):
         for n in net.nodes:
             if n.op == "embed":
                 ops.embed_fwd(P.grid, self.params[n.name + "/weights"], P.view(n.name, n.channels), P.oob)
+            elif n.op == "conv" and n is P.head:
+                # the logits layer, its norm, the softmax and (training) the CE + level 0 of the hard-negative select
+                a = n.attrs
+                src = n.inputs[0]
+                cin_pad = _pad(a["cin"], self.bke)
+                w = self.params[n.name + "/weights"]
+                if cin_pad != a["cin"]:
+                    raise NotImplementedError("logits head with cin %d not a multiple of %d" % (a["cin"], self.bke))
+                ops.head_fwd(P.view(src.name, cin_pad), cin_pad, w, self.params[n.name + "/biases"], self.C, P.head_a,
+                             P.head_stats, P.bufs[n.name], probs=P.probs.view(-1, self.C),
+                             labels=P.labels if labels is not None else None, ce=P.ce, bad=P.bad, workspace=P.head_ws)
+                P.fused[n.name] = False
             elif n.op == "conv":
                 a = n.attrs
                 src = n.inputs[0]
@@ -417,7 +473,8 @@ class Engine(object):
                         P.sync_fw[n.name] = torch.zeros(ops.conv_sync_bytes(B, P.stats[n.name].shape[1], n.channels) // 4,
                                                         dtype=torch.int32, device=self.dev)
                     P.fused[n.name] = ops.conv_in_fwd(seg, P.a[n.name][..., :n.channels], P.view(n.name, n.channels),
-                                                      n.channels, bias, act, P.stats[n.name], sync=P.sync_fw[n.name])
+                                                      n.channels, bias, act, P.stats[n.name], sync=P.sync_fw[n.name],
+                                                      late=P.late)
                 else:
                     P.fused[n.name] = False
                     ops.conv_fwd(seg, P.a[n.name], n.channels, bias=bias, relu=act, stats=P.stats[n.name])
@@ -439,6 +496,8 @@ class Engine(object):
                                      (B, H * W, n.channels),
                                      (P.view(n.name, n.channels).stride(0), P.view(n.name, n.channels).stride(2), 1)),
                                  oob=P.ps_oob)
+            elif n.op == "softmax" and P.head is not None and n.inputs[0] is P.head:
+                pass        # done by cutie_head_fwd
             elif n.op == "softmax":
                 src = n.inputs[0]
                 lab = P.labels if labels is not None else P.zero_labels
@@ -458,23 +517,34 @@ class Engine(object):
         return P.view(name, n.channels)
 
     def check_inputs(self, P):
-        """Host-side validation of the counters the kernels keep (one sync)."""
+        """Host-side validation of the counters the kernels keep (ONE device-to-host copy).  Call it after forward
+        (input errors) and / or after the step: the late-tile counter covers every conv launch since the forward began,
+        the backward ones included.  The device does not depend on this call: a step with late tiles is skipped by the
+        optimizer kernel itself and counted in opt_state[4] (steps_invalid())."""
         cnt = P.counters.cpu()
-        oob, bad, ps_oob = int(cnt[0]), int(cnt[1]) if P.has_labels else 0, int(cnt[2])
+        oob, bad, ps_oob, late = int(cnt[0]), int(cnt[1]) if P.has_labels else 0, int(cnt[2]), int(cnt[3])
         if ps_oob:
             raise CutieError("%d ps_1d_indices fall outside the image feature map (tf.batch_gather raises, "
                              "model_framework.py:83)" % ps_oob)
-        late = sum(int(s[0].item()) for s in list(P.sync.values()) + list(P.sync_fw.values()))
         if late:
-            raise CutieError("%d conv tiles gave up waiting for their sample's other tiles (the GPU could not hold a "
-                             "sample's workgroups at once): the gradients since the last check are invalid; set "
-                             "CUTIE_RENDEZVOUS=0 before loading the library" % late)
+            # the tiles' tags may have drifted apart: start every area of this plan from zero again
+            for t in list(P.sync.values()) + list(P.sync_fw.values()):
+                t.zero_()
+            P.late.zero_()
+            raise CutieError("%d conv waves gave up waiting for their sample's other tiles (the GPU could not hold a "
+                             "sample's workgroups at once - a shared or partitioned device?): the results of this "
+                             "step are invalid and the optimizer skipped it; set CUTIE_RENDEZVOUS=0 before loading "
+                             "the library to run without the in-launch tile meeting" % late)
         if oob:
             raise CutieError("%d grid cells hold a vocabulary id outside [0, %d) (SURVEY.md 0.7)" % (oob, self.net.num_vocabs))
         if bad:
             raise CutieError("%d labels fall outside [0, %d) (entity_class_id overflow, SURVEY.md 0.6)" % (bad, self.C))
 
-    def loss_backward(self, P, on_ready=None):
+    def steps_invalid(self):
+        """steps the device skipped because a conv tile's bounded wait ran out (one sync)"""
+        return int(self.opt_state[4].item())
+
+    def loss_backward(self, P, on_ready=None, defer_l2=None):
         """model_cutie.py:107-140 + tf.gradients: fills grads_flat (incl. the L2 term) and the
         squared global norm the way tf.clip_by_global_norm sees it.  Needs forward(labels=...).
 
@@ -483,7 +553,10 @@ class Engine(object):
         starts that slice's all-reduce while earlier layers still compute.  With the hook the conv
         range is left WITHOUT its L2 term (and, f16, still loss-scaled): the term is the same on
         every rank, so it is added once after the reduce - add_l2_after_reduce() - instead of by
-        fourteen small launches inside backward."""
+        fourteen small launches inside backward.
+
+        defer_l2 (default: with the hook only): leave grads_flat exactly as the gradient kernels wrote it - no L2 term,
+        f16 still loss-scaled - for apply_update(), which takes both in its own two passes."""
         if not P.has_labels:
             raise CutieError("loss_backward needs forward(..., labels=...)")
         self._plan_backward(P)
@@ -506,13 +579,23 @@ class Engine(object):
             ops.softmax_ce_fwd(P.ghm_z, P.labels, C, P.ce, P.ghm_probs, P.bad)
             ops.hnm_weights(P.ce, P.labels, int(spec["hard_negative_ratio"]), P.weight, P.loss, P.hnm_ws)
             ops.softmax_ce_bwd(P.ghm_probs, P.labels, P.weight, C, P.dy[lname][..., :C], ls, P.ghm_w)
+        elif P.head is not None:
+            # the rest of the select, d(loss)/d(logits), and the logits layer's norm + ReLU gradient: dz, bias partials, loss
+            ops.head_bwd(P.head_a, P.head_stats, P.bufs[lname], P.probs.view(-1, C), P.labels, P.ce, C,
+                         self.params[lname + "/biases"], int(spec["hard_negative_ratio"]), P.weight, P.head_red, P.loss,
+                         P.dz[lname], P.dbpart[lname], P.head_ws, loss_scale=ls)
         else:
             ops.hnm_weights(P.ce, P.labels, int(spec["hard_negative_ratio"]), P.weight, P.loss, P.hnm_ws)
             ops.softmax_ce_bwd(P.probs, P.labels, P.weight, C, P.dy[lname][..., :C], ls)
+        if defer_l2 is None:
+            defer_l2 = on_ready is not None
         # conv kernels and biases are overwritten by their gradient kernels (the padding between tensors is
-        # never written and stays zero); only the embedding gradient is accumulated into
-        self.grads_flat[self.n_dense:].zero_()
-        P.reg.zero_()
+        # never written and stays zero); only the embedding gradient is accumulated into - apply_update() leaves it cleared
+        if not getattr(self, "_embed_grad_clean", False):
+            self.grads_flat[self.n_dense:].zero_()
+        self._embed_grad_clean = False
+        if not defer_l2:
+            P.reg.zero_()
         wd = float(spec["weight_decay"])
         main = torch.cuda.current_stream(self.dev)
         side = None
@@ -548,7 +631,7 @@ class Engine(object):
         for n in reversed(net.nodes):
             if n.op == "conv":
                 a = n.attrs
-                have_dz = self._backprop_into(P, n) if n.name != lname else False
+                have_dz = self._backprop_into(P, n) if n.name != lname else (n is P.head)
                 if not have_dz:
                     dy = P.dy[n.name][..., :n.channels]
                     av, from_y = self._act_operand(P, n)
@@ -598,13 +681,46 @@ class Engine(object):
             for rows, batches in P._sum_rows_batches:
                 ops.replay_sum_rows(batches, rows, self.dev)
         P.reg_div = 1.0
-        P.l2_pending = on_ready is not None
-        if on_ready is None:
+        P.l2_pending = bool(defer_l2)
+        P.raw_grads = bool(defer_l2)       # apply_update() wants them so; add_l2_after_reduce() finishes them in place
+        if not defer_l2:
             ops.l2_add(self.params_flat[:self.n_conv_w], self.grads_flat[:self.n_conv_w], wd, P.reg, P.scratch, ls)
-        if ls is not None:
+        if ls is not None and not defer_l2:
             # biases and the embedding carry no L2 term: wd = 0 only takes the loss scale out
             ops.l2_add(self.params_flat[self.n_conv_w:], self.grads_flat[self.n_conv_w:], 0.0, P.reg, P.scratch, ls)
         return P
+
+    def apply_update(self, P, m, v, lr_t, beta1, beta2, eps, clip, world=1, t=0, emb_rows_sq=None,
+                     scale_growth_interval=1000):
+        """The optimizer tail of main_train_json.py:152-156 after loss_backward(defer_l2=True) (and, data parallel, the
+        all-reduce): L2 term, tf.clip_by_global_norm, Adam, the repack of the conv operands and the loss-scale update in
+        three launches (cutie_opt_norm, cutie_opt_step, cutie_loss_scale_update).  grads_flat holds the SUM of `world`
+        replicas' raw gradients.  emb_rows_sq: the embedding rows' share of the squared norm summed over the ranks
+        (Trainer.step); None = this replica's, taken inside the first pass.  A step whose norm is not finite (f16
+        overflow) or whose conv launches counted a late tile (P.late) changes nothing and is counted in opt_state.
+        Returns the 1-float device tensor of the squared global norm (of the summed gradient)."""
+        if not getattr(P, "raw_grads", False):
+            raise CutieError("apply_update needs loss_backward(..., defer_l2=True)")
+        wd = float(self.net.loss_spec["weight_decay"])
+        if getattr(self, "_opt_layers", None) is None:
+            names = sorted(self.conv_w_names, key=lambda k: self.offsets[k][0])
+            self._opt_layers = ops.opt_layers([(self.params[k], self.w_fwd[k], self.w_dg[k]) for k in names])
+            self._opt_partials = torch.zeros(capi.OPT_SCRATCH, dtype=torch.float32, device=self.dev)
+        rows = None
+        if emb_rows_sq is None and hasattr(P, "d_embed"):
+            rows = P.d_embed.reshape(-1)
+        ops.opt_norm(self.params_flat, self.grads_flat, self.n_conv_w, self.n_dense, wd * world, self._opt_partials,
+                     rows=rows, loss_scale=self.loss_scale)
+        ops.opt_step(self.params_flat, self.grads_flat, m, v, self.n_conv_w, wd * world, 0.5 * wd, self._opt_layers, self.dt,
+                     lr_t, beta1, beta2, eps, clip, 1.0 / world, t, self._opt_partials, extra_sq=emb_rows_sq,
+                     loss_scale=self.opt_state, invalid=P.late, gnorm_sq_out=P.gnorm_sq, reg_out=P.reg,
+                     zero_from=self.n_dense)
+        f16 = self.loss_scale is not None
+        ops.loss_scale_update(self.opt_state, P.gnorm_sq, backoff=0.5 if f16 else 1.0, growth=2.0 if f16 else 1.0,
+                              interval=scale_growth_interval, invalid=P.late)
+        P.reg_div, P.l2_pending, P.raw_grads = 1.0, False, False
+        self._embed_grad_clean = True      # cutie_opt_step cleared the embedding gradient behind itself
+        return P.gnorm_sq
 
     def add_l2_after_reduce(self, P, world=1):
         """Data-parallel tail of loss_backward(on_ready=...): the conv range holds the SUM of the ranks' gradients;
@@ -613,10 +729,15 @@ class Engine(object):
         if not getattr(P, "l2_pending", False):
             return
         wd = float(self.net.loss_spec["weight_decay"])
+        P.reg.zero_()
         ops.l2_add(self.params_flat[:self.n_conv_w], self.grads_flat[:self.n_conv_w], wd * world, P.reg, P.scratch,
                    self.loss_scale)
+        if self.loss_scale is not None:
+            # biases and the embedding carry no L2 term: wd = 0 only takes the loss scale out
+            ops.l2_add(self.params_flat[self.n_conv_w:], self.grads_flat[self.n_conv_w:], 0.0, P.reg, P.scratch, self.loss_scale)
         P.reg_div = float(world)       # the kernel's 0.5 * (world * wd) * sum(w^2) is world times the loss term
         P.l2_pending = False
+        P.raw_grads = False            # finished in place: cutie_adam_step's input, no longer apply_update()'s
 
     def embedding_rows_sumsq(self, P):
         """sum over this replica's grid cells of |d(embedding output) row|^2, loss scale taken out: the embedding's
@@ -646,9 +767,7 @@ class Engine(object):
 
     def loss_scale_value(self):
         """(S, steps skipped so far) - one sync; (1.0, 0) when the engine runs without a loss scale"""
-        if self.loss_scale is None:
-            return 1.0, 0
-        h = self.loss_scale.cpu()
+        h = self.opt_state.cpu()
         return float(h[0]), int(h[3])
 
     def losses(self, P):

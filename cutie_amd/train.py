@@ -15,7 +15,6 @@ import os
 
 import torch
 
-from . import ops
 from .parallel import GradBuckets, dist_info
 
 
@@ -49,33 +48,30 @@ class Trainer(object):
         P = eng.forward(batch["grid_table"], image=batch.get("data_image"), ps_1d_indices=batch.get("ps_1d_indices"),
                         labels=batch["gt_classes"])
         if self.check_inputs:
-            eng.check_inputs(P)
+            eng.check_inputs(P)            # bad ids / labels / sampler indices, before anything is trained on them
+        emb_sq = None
         if self.buckets is not None:
             # each bucket's all-reduce starts as soon as backward has finished its slice and runs
             # on the collective's stream under the remaining layers' dgrad/wgrad kernels
-            eng.loss_backward(P, on_ready=self.buckets.ready)
+            eng.loss_backward(P, on_ready=self.buckets.ready, defer_l2=True)
             # tf.clip_by_global_norm takes the embedding gradient as IndexedSlices: one row per grid cell, NOT summed
             # per id.  For the global batch those rows are the concatenation of every rank's rows, so
             # their squared norm is the SUM of the ranks' local ones: one more float in the last collective, and the
             # clip is the same function of the global batch at every world size.
             emb_sq = eng.embedding_rows_sumsq(P)
             self.buckets.finish(extra=emb_sq)
-            eng.add_l2_after_reduce(P, self.world)     # one launch over the reduced conv range
-            gn = eng.global_norm_sq(P, embedding_rows_sq=emb_sq)
         else:
-            eng.loss_backward(P)
-            gn = eng.global_norm_sq(P)
+            eng.loss_backward(P, defer_l2=True)
         self.t += 1
         lr_t = self.lr * math.sqrt(1.0 - self.b2 ** self.t) / (1.0 - self.b1 ** self.t)
-        # the host's t runs ahead of m and v by the steps the device skipped on an f16 overflow: the kernel takes
-        # them out of the bias correction (loss-scale state[3]); no host read-back
-        ops.adam_step(eng.params_flat, eng.grads_flat, self.m, self.v, lr_t, self.b1, self.b2, self.eps, gn,
-                      self.clip, grad_scale=1.0 / self.world, t=self.t, loss_scale=eng.loss_scale)
-        if eng.loss_scale is not None:
-            # f16: an overflowed backward made gn non-finite and Adam left everything untouched; halve
-            # the scale then, double it after a run of good steps - on the device, nobody waits
-            ops.loss_scale_update(eng.loss_scale, gn, interval=self.scale_growth_interval)
-        eng.repack()
+        # L2 term (world * wd * w beside the summed gradient), clip, Adam and the repack of the conv operands in two passes
+        # over the flat buffers.  The host's t runs ahead of m and v by the steps the device skipped - an f16 overflow, or
+        # conv tiles that gave up waiting for each other (P.late): the kernel takes them out of the bias correction
+        # (opt_state[3]) and leaves everything untouched on such a step; no host read-back
+        gn = eng.apply_update(P, self.m, self.v, lr_t, self.b1, self.b2, self.eps, self.clip, world=self.world, t=self.t,
+                              emb_rows_sq=emb_sq, scale_growth_interval=self.scale_growth_interval)
+        if self.check_inputs:
+            eng.check_inputs(P)            # late tiles of the whole step, backward included (the device skipped it already)
         self.iter += 1
         if not fetch:
             return None

@@ -158,7 +158,8 @@ int cutie_conv_in_fwd(const cutie_conv_seg* segs /* host */, int n_segs,
                       int B, int H, int W, int n_out,
                       void* a, int ld_a, void* y, int ld_y,
                       const float* bias, int relu, float* stats, int stats_tiles, float eps,
-                      void* sync, size_t sync_bytes, int* fused /* host, nullable */,
+                      void* sync, size_t sync_bytes, int32_t* late_count /* nullable, see cutie_conv_dgrad_in_bwd */,
+                      int* fused /* host, nullable */,
                       int dtype, cutie_stream_t stream);
 
 /* The data gradient of a layer that ends in the instance norm of model_framework.py:423, together with the
@@ -169,7 +170,9 @@ int cutie_conv_in_fwd(const cutie_conv_seg* segs /* host */, int n_segs,
  * not own are left alone - zero `red` once when it is allocated); otherwise the conv is followed by
  * cutie_in_bwd_stats over all red_tiles slots.  red_tiles >= cutie_conv_stats_tiles(H, W).
  * CUTIE_FUSE_NORM_BWD=0 in the environment WHEN THE LIBRARY IS LOADED selects the two-pass form (A/B
- * measurements; the library reads its three CUTIE_* switches once at load, never per call). */
+ * measurements; the library reads its four switches - CUTIE_CONV_WIDE, CUTIE_FUSE_NORM_BWD, CUTIE_CONV_LPT,
+ * CUTIE_RENDEZVOUS, each "0" to turn the named path off - once at load, never per call; none of them changes results
+ * beyond the rounding differences documented at the entry points). */
 int cutie_conv_dgrad_in_stats(const cutie_conv_seg* segs /* host */, int n_segs,
                               int B, int H, int W, int n_out,
                               void* out, int ld_out, int out_dtype,
@@ -191,7 +194,14 @@ int cutie_conv_dgrad_in_stats(const cutie_conv_seg* segs /* host */, int n_segs,
  *   sync: cutie_conv_sync_bytes(B, red_tiles, n_out) bytes, 64-byte aligned, zeroed ONCE by the caller and then left
  *         to the library, one area per (layer, shape): a launch's tag is the previous launch's + 1.  Word 0 counts
  *         waits that ran out (0.2 s: a sample's workgroups were not resident together) - the results of such a
- *         launch are invalid; read it at a synchronisation point.  NULL selects the two-call form.
+ *         launch are invalid; read it at a synchronisation point.  NULL selects the two-call form.  The library
+ *         remembers (on the host) the (B, red_tiles, n_out) an area was last used with and clears the area itself, on
+ *         the call's stream, when a call brings another geometry.
+ *   late_count (nullable): a device int32 of the caller's that is bumped together with word 0 - ONE word for all the
+ *         launches of a train step, cleared by the caller when the step starts and handed to cutie_opt_step /
+ *         cutie_adam_step / cutie_loss_scale_update as `invalid`: a step in which any tile gave up waiting is then
+ *         skipped on the device (parameters, moments and packed operands untouched, counted in the loss-scale state),
+ *         whether or not the host ever looks.
  *   dbias_part (nullable): dbias_tiles >= cutie_conv_stats_tiles(H, W); tile t of a sample STORES row t, rows the
  *         launch does not own are left alone (zero the array once when it is allocated), as for `red`.
  * CUTIE_RENDEZVOUS=0 in the environment when the library is loaded selects the two-call form everywhere. */
@@ -203,7 +213,7 @@ int cutie_conv_dgrad_in_bwd(const cutie_conv_seg* segs /* host */, int n_segs,
                             float* red, int red_tiles, int relu,
                             const float* shift_bias /* with `relu`: the shift of `stats`, see K6 */,
                             void* dz, int ld_dz, float* dbias_part, int dbias_tiles,
-                            void* sync, size_t sync_bytes,
+                            void* sync, size_t sync_bytes, int32_t* late_count /* nullable */,
                             int dtype, cutie_stream_t stream);
 
 /* weight gradient: dw[(i*kw+j)][c][n] (= HWIO, model_framework.py:416) =
@@ -350,6 +360,44 @@ int cutie_softmax_ce_bwd(const float* probs, const int32_t* labels, const float*
                          const float* elem_weight /* nullable f32 [n_cells][C]: GHM, below */,
                          cutie_stream_t stream);
 
+/* The logits head in a handful of small launches (16-bit activations, C <= 32 classes, ReLU).   Replaces, for the
+ * last layer of every CUTIE graph, Model.conv(1, 1, C) + bias + ReLU + instance norm (model_cutie_aspp.py:72-73,
+ * model_framework.py:414-424), Model.softmax (:318-320) and CUTIE.build_loss (model_cutie.py:107-130) - the same
+ * arithmetic as cutie_conv_fwd + cutie_in_apply + cutie_softmax_ce_fwd + cutie_hnm_weights + cutie_softmax_ce_bwd +
+ * cutie_in_bwd_stats + cutie_in_bwd_apply on that layer, with the pre-norm activation kept in f32.
+ * fwd:  a[n][0..C) = relu(x[n][0..cin) . w_hwio[cin][C] + bias) (MFMA, 16-bit operands, f32 accumulate; f32 out, ld_a a
+ *       multiple of 4, columns C..ld_a of `a` and `logits` receive zeros); stats [B][stats_tiles][C][2] = per
+ *       256-pixel tile (sum, sum of squares) of a - relu(bias) (K6's shifted moments; stats_tiles >=
+ *       cutie_head_tiles(HW), the other slots are left alone: zero the array once);
+ *       logits = instance_norm(a), probs[n][0..C) = softmax(logits[n]) (nullable), and with labels (int8 as the loader's
+ *       grid, data_loader_json.py:455, or int32: label_bytes 1 / 4) ce[n] and *bad_labels as cutie_softmax_ce_fwd, plus
+ *       level 0 of the hard-negative select in the workspace.  The softmax and the CE are wavefront reductions: eight
+ *       lanes share a cell, four classes each.  labels == NULL: inference (ce, bad_labels, workspace unused).
+ * bwd:  the rest of the select (ties to the lower index, as tf.nn.top_k), weight[n] and loss_out[0..3) as
+ *       cutie_hnm_weights; red [B][cutie_head_chunks(HW)][C][2] = partial (sum dy, sum dy * logits) with
+ *       dy = S * weight * (probs - onehot); dz[n][c] = [a > 0] * inv * (dy - mean(dy) - logits * mean(dy * logits)) in
+ *       dz_dtype (ld_dz a multiple of 4; columns beyond C of a group of four that starts below C receive zeros, the
+ *       others are left alone); dbias_part (nullable) [B * cutie_head_chunks(HW)][C] partial sums of dz.
+ *       Must follow cutie_head_fwd on the same stream with the same workspace (>= cutie_head_workspace_bytes(B, HW)
+ *       bytes, 16-byte aligned, clobbered; no pre-fill).  Deterministic: every sum is taken in a fixed order. */
+int cutie_head_tiles(int HW);
+int cutie_head_chunks(int HW);
+size_t cutie_head_workspace_bytes(int B, int HW);
+int cutie_head_fwd(const void* x, int ld_x, int dtype, int B, int HW, int cin,
+                   const float* w_hwio, const float* bias, int C, float eps,
+                   float* a, int ld_a, float* stats, int stats_tiles,
+                   float* logits, int ld_logits, float* probs,
+                   const void* labels /* nullable */, int label_bytes, float* ce, int32_t* bad_labels,
+                   void* workspace, size_t workspace_bytes, cutie_stream_t stream);
+int cutie_head_bwd(const float* a, int ld_a, const float* stats, int stats_tiles,
+                   const float* logits, int ld_logits, const float* probs,
+                   const void* labels, int label_bytes, const float* ce,
+                   int B, int HW, int C, float eps, const float* bias, int ratio,
+                   const float* loss_scale /* nullable */,
+                   float* weight, float* red, float* loss_out,
+                   void* dz, int ld_dz, int dz_dtype, float* dbias_part /* nullable */,
+                   void* workspace, size_t workspace_bytes, cutie_stream_t stream);
+
 /* Gradient harmonising weights (use_ghm = 1).   Replaces calc_ghm_weights, main_train_json.py:86-119,
  * and the product cls_logits * ghm_weights of model_cutie.py:110.
  *   grad = |logit - onehot| per (cell, class); bin i: i/bins <= grad < (i+1)/bins (last edge + eps);
@@ -381,7 +429,7 @@ int cutie_ghm_weights(const void* logits, int ld, int dtype, const int32_t* labe
  *
  * Loss scale (no counterpart in the reference, which trains in f32; it is what lets the CUTIE_F16
  * path keep the gradients the reference computes instead of flushing them to zero): a device
- * array `loss_scale` = {S, 1/S, good steps in a row, steps skipped}.  cutie_softmax_ce_bwd
+ * array `loss_scale` = {S, 1/S, good steps in a row, steps skipped, ...} of CUTIE_LOSS_SCALE_STATE floats.  cutie_softmax_ce_bwd
  * multiplies dlogits by S, so every activation gradient, weight gradient and bias gradient of the
  * backward pass carries S; cutie_l2_add (g = g/S + wd*w) and cutie_sumsq (sum/S^2) take it out
  * again when they are handed the same array.  NULL means S = 1 everywhere.
@@ -394,14 +442,49 @@ int cutie_l2_add(const float* w, float* g, int64_t n, float wd, float* reg_loss,
                  const float* loss_scale /* nullable */, cutie_stream_t stream);
 int cutie_sumsq(const void* x, int64_t n, int dtype, float* out, float* scratch,
                 const float* loss_scale /* nullable */, cutie_stream_t stream);
-int cutie_loss_scale_init(float* state /* device, 4 floats */, float scale, cutie_stream_t stream);
+#define CUTIE_LOSS_SCALE_STATE 8 /* floats: {S, 1/S, good steps in a row, steps skipped, of them invalid, -, -, -} */
+int cutie_loss_scale_init(float* state /* device, CUTIE_LOSS_SCALE_STATE floats */, float scale, cutie_stream_t stream);
+/* `invalid` (nullable, device int32): the step-wide late_count of the conv entry points.  Non-zero = the step's
+ * results are not to be trusted: Adam leaves p, m, v untouched, the update counts the step as skipped (state[3],
+ * state[4]) and leaves S alone. */
 int cutie_loss_scale_update(float* state, const float* gnorm_sq, float backoff, float growth,
-                            int interval, float min_scale, float max_scale, cutie_stream_t stream);
+                            int interval, float min_scale, float max_scale, const int32_t* invalid,
+                            cutie_stream_t stream);
 int cutie_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr_t,
                     float beta1, float beta2, float eps, const float* gnorm_sq, float clip,
                     float grad_scale, int t /* the caller's step count behind lr_t; 0 = take lr_t as it is */,
                     const float* loss_scale /* nullable: lr_t is re-based to step t - (steps the device skipped) */,
-                    cutie_stream_t stream);
+                    const int32_t* invalid /* nullable */, cutie_stream_t stream);
+
+/* The same tail - L2 term, global-norm clip, Adam, the repack of the conv operands - as TWO launches over the flat
+ * buffers (main_train_json.py:152-156; l2_regularizer model_framework.py:427-432).  The gradient buffer is left as
+ * backward wrote it (no L2 term added in place, still loss-scaled):
+ *   norm:  partials[0..1023]    = per-workgroup sums of (g/S + wd*w)^2 over [0, n_l2), (g/S)^2 over [n_l2, n_dense),
+ *                                 plus (rows/S)^2 over `rows` (nullable; the embedding's IndexedSlices rows, one per
+ *                                 grid cell, in rows_dtype - how tf.clip_by_global_norm sees that gradient);
+ *          partials[1024..2047] = per-workgroup sums of w^2 over [0, n_l2).   CUTIE_OPT_SCRATCH floats.
+ *   step:  every workgroup folds the partials in one fixed order (+ *extra_sq, nullable: a share of the squared norm
+ *          that was summed elsewhere, e.g. over data-parallel ranks), so all of them hold the same bits;
+ *          g' = (g/S + wd_i*w) * grad_scale * clip / max(|g| * grad_scale, clip), wd_i = wd on [0, n_l2) else 0;
+ *          Adam as cutie_adam_step.  `layers` (host array, device pointers inside; w_hwio must point INTO p, in
+ *          ascending order, inside [0, n_l2)) are walked in 64 x 64 (cin x cout) tiles whose updated values also go,
+ *          in `dtype`, to w_dgrad [tap][cin][cout_pad] and transposed to w_fwd [tap][cout][cin_pad]
+ *          (cutie_pack_weights_batched's layouts; no separate repack).  Elements of [0, n_l2) outside every layer are
+ *          padding and are left alone.  *gnorm_sq_out = the folded squared norm, *reg_out = reg_scale * sum w^2
+ *          (both nullable).  g[zero_from .. n) is cleared after use (zero_from < 0: nothing) - the scatter-added
+ *          embedding gradient starts the next step at zero without a fill of its own.
+ *          A non-finite norm or *invalid != 0 leaves p, m, v and the packed operands untouched (g[zero_from .. n) is
+ *          cleared all the same). */
+#define CUTIE_OPT_SCRATCH 2048
+int cutie_opt_norm(const float* w, const float* g, int64_t n_l2, int64_t n_dense, float wd,
+                   const void* rows, int64_t n_rows, int rows_dtype, const float* loss_scale /* nullable */,
+                   float* partials, cutie_stream_t stream);
+int cutie_opt_step(float* p, float* g, float* m, float* v, int64_t n, int64_t n_l2, float wd, float reg_scale,
+                   const struct cutie_pack_desc* layers /* host */, int n_layers, int dtype,
+                   float lr_t, float beta1, float beta2, float eps, float clip, float grad_scale, int t,
+                   const float* partials, const float* extra_sq /* nullable */,
+                   float* loss_scale /* nullable */, const int32_t* invalid /* nullable */,
+                   float* gnorm_sq_out, float* reg_out, int64_t zero_from, cutie_stream_t stream);
 
 /* K13  Model.positional_sampling, model_framework.py:73-86 (tf.batch_gather):
  * out[b, cell, :] = feat[b, idx[b, cell], :].  An index outside [0, n_src) is clamped into it and bumps *oob_count

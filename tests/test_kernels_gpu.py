@@ -1017,7 +1017,7 @@ def test_loss_scale_state_machine(ops):
     the Adam step and halves S, a run of finite steps doubles it - all without a host round trip."""
     g = torch.Generator().manual_seed(21)
     ls = ops.loss_scale_state(1024.0, DEV)
-    assert ls.cpu().tolist() == [1024.0, 1.0 / 1024.0, 0.0, 0.0]
+    assert ls.cpu().tolist()[:4] == [1024.0, 1.0 / 1024.0, 0.0, 0.0]
     n, C = 1000, 18
     probs = torch.softmax(torch.randn((n, C), generator=g), dim=-1).to(DEV)
     labels = torch.randint(0, C, (n,), generator=g, dtype=torch.int32).to(DEV)
@@ -1060,10 +1060,10 @@ def test_loss_scale_state_machine(ops):
     # the scale itself
     ninf = torch.full((1,), float("inf"), dtype=torch.float32, device=DEV)
     ops.loss_scale_update(ls, ninf, interval=3)
-    assert ls.cpu().tolist() == [512.0, 1.0 / 512.0, 0.0, 1.0]
+    assert ls.cpu().tolist()[:4] == [512.0, 1.0 / 512.0, 0.0, 1.0]
     for k in range(3):
         ops.loss_scale_update(ls, nsq, interval=3)
-    assert ls.cpu().tolist() == [1024.0, 1.0 / 1024.0, 0.0, 1.0]
+    assert ls.cpu().tolist()[:4] == [1024.0, 1.0 / 1024.0, 0.0, 1.0]
     ops.loss_scale_update(ls, nsq, interval=3)
     assert ls.cpu().tolist()[2] == 1.0
     for k in range(40):                                              # clamps at both ends
