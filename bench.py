@@ -30,7 +30,7 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
 BF16_PEAK_TFLOPS = 2516.6     # MI355X dense bf16 MFMA: 256 CU x 2.4 GHz x 4096 FLOP/clk/CU
-PRIME = 20                    # untimed steps before the warm-up (start-up transient, see main)
+PRIME = 8                     # untimed steps before the warm-up: the device's first ~6 steps run 9.4 -> 7.9 ms (clock ramp, cold caches)
 GF_PER_DOC_INBOUNDS = 231.743  # CUTIE-ASPP 64x64 fwd+bwd, in-bounds taps only
 
 
@@ -238,9 +238,10 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    # Start-up transient: one step among the first ~10 after process start takes ~38 ms instead of
-    # 9 (runtime-side pool growth; tools/step_series.py shows it with and without weight updates).
-    # PRIME untimed steps keep it out of short runs; they come on top of the W warm-up steps.
+    # Start-up: the device's own step time is flat from about the sixth step on (tools/step_trace.py: 9.40 8.44 8.21 8.04
+    # 7.88 7.81 7.79 7.73 7.72 ... ms).  The "38 ms step" of rounds 1 and 2 was a generation-2 pass of Python's garbage
+    # collector (39.5 ms of host time over torch's object graph): Trainer freezes the long-lived objects after its first
+    # step, so no such pass falls into the timed region.  PRIME untimed steps come on top of the W warm-up steps.
     for _ in range(PRIME):
         step()
     for _ in range(args.warmup):

@@ -94,11 +94,11 @@ __device__ __forceinline__ unsigned sortable(float f) {
 //   with the largest ce, ties broken toward the lower index (tf.nn.top_k).  The num_bg-th largest
 //   key is found by a three-level radix select (11 + 11 + 10 bits of the order-preserving integer
 //   image of the float) - one histogram kernel per level, every workgroup redoing the small bin
-//   scan of the previous level - then the cells equal to the threshold are counted per 1024-cell
+//   scan of the previous level - then the cells equal to the threshold are counted per 256-cell
 //   chunk so that the final kernel can take the first k_eq of them in index order.
 //   All sums are fixed-order (per-chunk partials, then one thread): the loss is deterministic.
 constexpr int HNM_T = 256;
-constexpr int HNM_CHUNK = 1024;       // cells per workgroup (4 per lane)
+constexpr int HNM_CHUNK = 256;        // cells per workgroup (one per lane; 1024 in round 2: a quarter of the workgroups, each four times as long, on kernels that are pure latency)
 constexpr int HNM_B0 = 2048, HNM_B1 = 2048, HNM_B2 = 1024;
 
 struct HnmWs {
@@ -109,8 +109,11 @@ struct HnmWs {
     int* tie_cnt;    // [chunks]
     float* sum_fg;   // [chunks]
     float* sum_sel;  // [chunks]
+    int* cnt_fg;     // [chunks]   per-chunk cell counts, STORED by level 0 (512 workgroups adding to two words by atomics
+    int* cnt_bg;     // [chunks]   queue up behind each other); level 1 sums them and leaves the totals in counts[0..1]
 };
 constexpr int HNM_INT_HEAD = 8 + HNM_B0 + HNM_B1 + HNM_B2;
+constexpr int HNM_PER_CHUNK = 5;      // words per chunk behind the head
 
 __device__ __forceinline__ HnmWs hnm_ws(void* ws, int chunks) {
     HnmWs w;
@@ -121,6 +124,8 @@ __device__ __forceinline__ HnmWs hnm_ws(void* ws, int chunks) {
     w.tie_cnt = w.hist2 + HNM_B2;
     w.sum_fg = reinterpret_cast<float*>(w.tie_cnt + chunks);
     w.sum_sel = w.sum_fg + chunks;
+    w.cnt_fg = reinterpret_cast<int*>(w.sum_sel + chunks);
+    w.cnt_bg = w.cnt_fg + chunks;
     return w;
 }
 
@@ -140,6 +145,12 @@ __device__ __forceinline__ float block_sum_f256(float v, float* sh) {
     return ((sh[0] + sh[1]) + sh[2]) + sh[3];
 }
 
+__device__ __forceinline__ long long hnm_num_bg(long long nfg, long long nbg, int ratio, bool& all_bg) {
+    const long long want = (long long)ratio * nfg;
+    const long long num_bg = want < nbg ? want : nbg;     // model_cutie.py:124-125
+    all_bg = num_bg == nbg;
+    return num_bg;
+}
 __device__ __forceinline__ long long hnm_num_bg(const int* counts, int ratio, bool& all_bg) {
     const long long nfg = counts[0], nbg = counts[1];
     const long long want = (long long)ratio * nfg;
@@ -190,8 +201,8 @@ __device__ __forceinline__ void hnm_select(const int* __restrict__ hist, int bin
     __syncthreads();
 }
 
-// Cells of the flattened batch as 1024-cell chunks that never straddle a sample: chunk (b, cs) covers cells
-// b*HW + cs*1024 .. of sample b (the last chunk of a sample may be short).  Chunk ids grow with the cell index, so
+// Cells of the flattened batch as HNM_CHUNK-cell chunks that never straddle a sample: chunk (b, cs) covers cells
+// b*HW + cs*HNM_CHUNK .. of sample b (the last chunk of a sample may be short).  Chunk ids grow with the cell index, so
 // "index order" is chunk order, then position.  The flat entry points run with one sample of n_cells cells.
 struct CellMap {
     long long HW;
@@ -234,8 +245,8 @@ __global__ __launch_bounds__(HNM_T) void hnm_count_kernel(const float* __restric
     nbg = block_sum_i256(nbg, shi);
     sum_fg = block_sum_f256(sum_fg, shf);
     if (tid == 0) {
-        if (nfg) atomicAdd(&ws.counts[0], nfg);
-        if (nbg) atomicAdd(&ws.counts[1], nbg);
+        ws.cnt_fg[blockIdx.x] = nfg;
+        ws.cnt_bg[blockIdx.x] = nbg;
         ws.sum_fg[blockIdx.x] = sum_fg;
     }
     for (int i = tid; i < HNM_B0; i += HNM_T)
@@ -253,7 +264,18 @@ __global__ __launch_bounds__(HNM_T) void hnm_hist_kernel(const float* __restrict
     const HnmWs ws = hnm_ws(ws_, chunks);
     const int tid = threadIdx.x;
     bool all_bg;
-    const long long num_bg = hnm_num_bg(ws.counts, ratio, all_bg);
+    long long num_bg;
+    if (LEVEL == 1) {
+        // the totals of level 0's per-chunk counts: every workgroup adds them for itself, workgroup 0 leaves them in
+        // counts[0..1] for the kernels that follow
+        int pf = 0, pb = 0;
+        for (int c = tid; c < chunks; c += HNM_T) { pf += ws.cnt_fg[c]; pb += ws.cnt_bg[c]; }
+        const int nfg = block_sum_i256(pf, sh), nbg = block_sum_i256(pb, sh);
+        if (blockIdx.x == 0 && tid == 0) { ws.counts[0] = nfg; ws.counts[1] = nbg; }
+        num_bg = hnm_num_bg((long long)nfg, (long long)nbg, ratio, all_bg);
+    } else {
+        num_bg = hnm_num_bg(ws.counts, ratio, all_bg);
+    }
     if (all_bg || num_bg <= 0) return;
     unsigned prefix;     // the key bits fixed so far, right-aligned
     if (LEVEL == 1) {
@@ -398,19 +420,37 @@ __global__ __launch_bounds__(HNM_T) void hnm_weight_kernel(const float* __restri
     const float S = hr.loss_scale ? hr.loss_scale[0] : 1.f;
     float r1[4] = {0.f, 0.f, 0.f, 0.f}, r2[4] = {0.f, 0.f, 0.f, 0.f};
     if (q * 4 < hr.C) {
-        for (int pass = 0; pass < HNM_CHUNK / 32; ++pass) {
-            const float w = wsh[pass * 32 + g];
-            if (w == 0.f) continue;
-            bool in;
-            const long long i = chunk_cell(cm, blockIdx.x, pass * 32 + g, in);
-            const int lab = label_at(labels, label_bytes, i);
+        constexpr int NP = HNM_CHUNK / 32;
+        float wq[NP], pq[NP][4];
+        float4 yq[NP];
+        int lq[NP];
+#pragma unroll
+        for (int pass = 0; pass < NP; ++pass) {      // the loads of every weighted cell in flight together
+            wq[pass] = wsh[pass * 32 + g];
+            yq[pass] = make_float4(0.f, 0.f, 0.f, 0.f);
+            lq[pass] = -1;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) pq[pass][e] = 0.f;
+            if (wq[pass] != 0.f) {
+                bool in;
+                const long long i = chunk_cell(cm, blockIdx.x, pass * 32 + g, in);
+                lq[pass] = label_at(labels, label_bytes, i);
+                yq[pass] = *reinterpret_cast<const float4*>(hr.logits + i * hr.ld_l + q * 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) if (q * 4 + e < hr.C) pq[pass][e] = hr.probs[i * hr.C + q * 4 + e];
+            }
+        }
+#pragma unroll
+        for (int pass = 0; pass < NP; ++pass) {
+            if (wq[pass] == 0.f) continue;
+            const float ye[4] = {yq[pass].x, yq[pass].y, yq[pass].z, yq[pass].w};
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int c = q * 4 + e;
                 if (c < hr.C) {
-                    const float dy = S * w * (hr.probs[i * hr.C + c] - (lab == c ? 1.f : 0.f));
+                    const float dy = S * wq[pass] * (pq[pass][e] - (lq[pass] == c ? 1.f : 0.f));
                     r1[e] += dy;
-                    r2[e] = __builtin_fmaf(dy, hr.logits[i * hr.ld_l + c], r2[e]);
+                    r2[e] = __builtin_fmaf(dy, ye[e], r2[e]);
                 }
             }
         }
@@ -427,21 +467,26 @@ __global__ __launch_bounds__(HNM_T) void hnm_weight_kernel(const float* __restri
     }
 }
 
-__device__ __forceinline__ void hnm_final(const HnmWs& ws, int chunks, int ratio, float* __restrict__ loss_out) {
+// the loss from the per-chunk sums: all 256 lanes of a workgroup take part (lane t adds chunks t, t + 256, ...; the lane sums
+// are then added in a fixed order), lane 0 writes.  sh: 4 floats.
+__device__ __forceinline__ void hnm_final(const HnmWs& ws, int chunks, int ratio, float* __restrict__ loss_out, float* sh) {
     bool all_bg;
     const long long num_bg = hnm_num_bg(ws.counts, ratio, all_bg);
     float sum_fg = 0.f, sum_sel = 0.f;
-    for (int c = 0; c < chunks; ++c) { sum_fg += ws.sum_fg[c]; sum_sel += ws.sum_sel[c]; }
+    for (int c = threadIdx.x; c < chunks; c += HNM_T) { sum_fg += ws.sum_fg[c]; sum_sel += ws.sum_sel[c]; }
+    sum_fg = block_sum_f256(sum_fg, sh);
+    sum_sel = block_sum_f256(sum_sel, sh);
+    if (threadIdx.x != 0) return;
     // mean over an empty set is NaN (tf.reduce_mean of an empty tensor): 0/0
     loss_out[0] = sum_fg / (float)ws.counts[0] + sum_sel / (float)num_bg;
     loss_out[1] = (float)ws.counts[0];
     loss_out[2] = (float)num_bg;
 }
 
-__global__ __launch_bounds__(64) void hnm_final_kernel(int chunks, int ratio, void* ws_, float* __restrict__ loss_out) {
+__global__ __launch_bounds__(HNM_T) void hnm_final_kernel(int chunks, int ratio, void* ws_, float* __restrict__ loss_out) {
+    __shared__ float sh[4];
     const HnmWs ws = hnm_ws(ws_, chunks);
-    if (threadIdx.x != 0) return;
-    hnm_final(ws, chunks, ratio, loss_out);
+    hnm_final(ws, chunks, ratio, loss_out, sh);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -550,8 +595,11 @@ __device__ __forceinline__ float hd_row16_sum(float v) {      // sum over the 16
 template <int DT>
 __global__ __launch_bounds__(256) void head_conv_kernel(const typename elem<DT>::type* __restrict__ x, int ld_x, int HW, int cin,
                                                         const float* __restrict__ w, const float* __restrict__ bias, int C,
-                                                        float* __restrict__ a, int ld_a, float* __restrict__ stats, int tiles) {
+                                                        float* __restrict__ a, int ld_a, float* __restrict__ stats, int tiles,
+                                                        int* __restrict__ ws_zero, int ws_words) {
     typedef typename elem<DT>::type T;
+    // the select's counters and histograms start at zero (this launch precedes head_norm_ce_kernel, which adds to them)
+    for (int i = (blockIdx.y * gridDim.x + blockIdx.x) * 256 + threadIdx.x; i < ws_words; i += gridDim.x * gridDim.y * 256) ws_zero[i] = 0;
     __shared__ uint4 wf[2][HEAD_MAX_KK][64];
     __shared__ float2 wsum[4][32];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -627,15 +675,44 @@ __global__ __launch_bounds__(256) void head_conv_kernel(const typename elem<DT>:
     }
 }
 
+// Sum of the T slots of a [T][C][2] partial-sum array for channel lanes tid < 32 (C <= 32), in slot order (norm.hip's
+// fold), with the loads spread over the workgroup: eight slots per round trip instead of one.  lds: [8][32] float2.
+__device__ __forceinline__ void fold_slots_par(const float* __restrict__ base, int T, int C, float2* lds, float& s, float& ss) {
+    const int tid = threadIdx.x, c = tid & 31, tr = tid >> 5;
+    s = 0.f;
+    ss = 0.f;
+    for (int t0 = 0; t0 < T; t0 += 8) {
+        float2 v = make_float2(0.f, 0.f);
+        if (t0 + tr < T && c < C) v = *reinterpret_cast<const float2*>(base + ((long long)(t0 + tr) * C + c) * 2);
+        __syncthreads();
+        lds[tr * 32 + c] = v;
+        __syncthreads();
+        if (tid < 32) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { s += lds[k * 32 + tid].x; ss += lds[k * 32 + tid].y; }
+        }
+    }
+}
+
+// reductions over the eight lanes that share a cell, on the vector ALU (DPP: quad xor 1, quad xor 2, half-row mirror);
+// every lane of the group ends up with the result
+__device__ __forceinline__ float dpp_mov(float v, int ctrl_b1, int ctrl_4e, int ctrl_141, int which) {
+    const int x = __builtin_bit_cast(int, v);
+    int r;
+    if (which == 0) r = __builtin_amdgcn_update_dpp(0, x, 0xB1, 0xF, 0xF, true);
+    else if (which == 1) r = __builtin_amdgcn_update_dpp(0, x, 0x4E, 0xF, 0xF, true);
+    else r = __builtin_amdgcn_update_dpp(0, x, 0x141, 0xF, 0xF, true);
+    return __builtin_bit_cast(float, r);
+}
 __device__ __forceinline__ float grp8_max(float v) {
-    v = fmaxf(v, __shfl_xor(v, 1, 64));
-    v = fmaxf(v, __shfl_xor(v, 2, 64));
-    return fmaxf(v, __shfl_xor(v, 4, 64));
+    v = fmaxf(v, dpp_mov(v, 0, 0, 0, 0));
+    v = fmaxf(v, dpp_mov(v, 0, 0, 0, 1));
+    return fmaxf(v, dpp_mov(v, 0, 0, 0, 2));
 }
 __device__ __forceinline__ float grp8_sum(float v) {
-    v += __shfl_xor(v, 1, 64);
-    v += __shfl_xor(v, 2, 64);
-    return v + __shfl_xor(v, 4, 64);
+    v += dpp_mov(v, 0, 0, 0, 0);
+    v += dpp_mov(v, 0, 0, 0, 1);
+    return v + dpp_mov(v, 0, 0, 0, 2);
 }
 
 // grid (chunks per sample, B), 256 lanes: a wave takes eight cells at a time, eight lanes to a cell, four classes to
@@ -653,17 +730,12 @@ __global__ __launch_bounds__(HNM_T) void head_norm_ce_kernel(const float* __rest
     __shared__ float shf[4];
     const int tid = threadIdx.x;
     const int b = blockIdx.y, chunk = b * gridDim.x + blockIdx.x;
+    __shared__ float2 fold[8 * 32];
+    float fs, fss;
+    fold_slots_par(stats + (long long)b * tiles * C * 2, tiles, C, fold, fs, fss);
     if (tid < 32) {
         float mean = 0.f, inv = 0.f;
-        if (tid < C) {
-            float s = 0.f, ss = 0.f;
-            for (int t = 0; t < tiles; ++t) {      // slot order, as norm.hip's fold
-                const float2 v = *reinterpret_cast<const float2*>(stats + (((long long)b * tiles + t) * C + tid) * 2);
-                s += v.x;
-                ss += v.y;
-            }
-            norm_mean_inv(s, ss, 1.f / (float)cm.HW, norm_shift(bias, 1, tid), eps, mean, inv);
-        }
+        if (tid < C) norm_mean_inv(fs, fss, 1.f / (float)cm.HW, norm_shift(bias, 1, tid), eps, mean, inv);
         tab[0][tid] = mean;
         tab[1][tid] = inv;
     }
@@ -675,12 +747,24 @@ __global__ __launch_bounds__(HNM_T) void head_norm_ce_kernel(const float* __rest
     for (int e = 0; e < 4; ++e) { mean[e] = tab[0][q * 4 + e]; inv[e] = tab[1][q * 4 + e]; }
     int nfg = 0, nbg = 0;
     float sum_fg = 0.f;
-    for (int pass = 0; pass < HNM_CHUNK / 32; ++pass) {
+    constexpr int NP = HNM_CHUNK / 32;      // passes: 32 cells at a time, all loads of the chunk in flight together
+    float4 av[NP];
+    int labv[NP];
+#pragma unroll
+    for (int pass = 0; pass < NP; ++pass) {
+        bool in;
+        const long long i = chunk_cell(cm, chunk, pass * 32 + g, in);
+        av[pass] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (in && q * 4 < ld_a) av[pass] = *reinterpret_cast<const float4*>(a + i * ld_a + q * 4);
+        labv[pass] = (labels && in) ? label_at(labels, label_bytes, i) : 0;
+    }
+#pragma unroll
+    for (int pass = 0; pass < NP; ++pass) {
         bool in;
         const long long i = chunk_cell(cm, chunk, pass * 32 + g, in);
         float y[4] = {0.f, 0.f, 0.f, 0.f};
         if (in && q * 4 < ld_a) {
-            const float4 v = *reinterpret_cast<const float4*>(a + i * ld_a + q * 4);
+            const float4 v = av[pass];
             y[0] = (v.x - mean[0]) * inv[0]; y[1] = (v.y - mean[1]) * inv[1];
             y[2] = (v.z - mean[2]) * inv[2]; y[3] = (v.w - mean[3]) * inv[3];
         }
@@ -699,7 +783,7 @@ __global__ __launch_bounds__(HNM_T) void head_norm_ce_kernel(const float* __rest
             for (int e = 0; e < 4; ++e) if (q * 4 + e < C) probs[i * C + q * 4 + e] = ex[e] * r;
         }
         if (!labels) continue;
-        const int lab = in ? label_at(labels, label_bytes, i) : 0;
+        const int lab = labv[pass];
         float yl = 0.f;
 #pragma unroll
         for (int e = 0; e < 4; ++e) if (q * 4 + e == lab) yl = y[e];
@@ -719,8 +803,8 @@ __global__ __launch_bounds__(HNM_T) void head_norm_ce_kernel(const float* __rest
     nbg = block_sum_i256(nbg, shi);
     sum_fg = block_sum_f256(sum_fg, shf);
     if (tid == 0) {
-        if (nfg) atomicAdd(&ws.counts[0], nfg);
-        if (nbg) atomicAdd(&ws.counts[1], nbg);
+        ws.cnt_fg[chunk] = nfg;
+        ws.cnt_bg[chunk] = nbg;
         ws.sum_fg[chunk] = sum_fg;
     }
     for (int i = tid; i < HNM_B0; i += HNM_T)
@@ -744,29 +828,29 @@ __global__ __launch_bounds__(HNM_T) void head_bwd_kernel(const float* __restrict
     __shared__ float racc[32][32];
     const int tid = threadIdx.x;
     const int b = blockIdx.y, chunk = b * gridDim.x + blockIdx.x;
-    if (chunk == 0 && tid == 0) hnm_final(hnm_ws(ws_, chunks), chunks, ratio, loss_out);
+    if (chunk == 0) {
+        __shared__ float shfin[4];
+        hnm_final(hnm_ws(ws_, chunks), chunks, ratio, loss_out, shfin);
+    }
+    __shared__ float2 fold[8 * 32];
+    float fs, fss, r1, r2;
+    fold_slots_par(stats + (long long)b * tiles * C * 2, tiles, C, fold, fs, fss);
+    fold_slots_par(red + (long long)b * cm.cps * C * 2, cm.cps, C, fold, r1, r2);
     if (tid < 32) {
-        float inv = 0.f, m1 = 0.f, m2 = 0.f;
+        float inv = 0.f;
         if (tid < C) {
-            float s = 0.f, ss = 0.f, mean;
-            for (int t = 0; t < tiles; ++t) {
-                const float2 v = *reinterpret_cast<const float2*>(stats + (((long long)b * tiles + t) * C + tid) * 2);
-                s += v.x;
-                ss += v.y;
-            }
+            float mean;
             const float inv_n = 1.f / (float)cm.HW;
-            norm_mean_inv(s, ss, inv_n, norm_shift(bias, 1, tid), eps, mean, inv);
-            for (int t = 0; t < cm.cps; ++t) {
-                const float2 v = *reinterpret_cast<const float2*>(red + (((long long)b * cm.cps + t) * C + tid) * 2);
-                m1 += v.x;
-                m2 += v.y;
-            }
-            m1 *= inv_n;
-            m2 *= inv_n;
+            norm_mean_inv(fs, fss, inv_n, norm_shift(bias, 1, tid), eps, mean, inv);
+            r1 *= inv_n;
+            r2 *= inv_n;
+        } else {
+            r1 = 0.f;
+            r2 = 0.f;
         }
         tab[0][tid] = inv;
-        tab[1][tid] = m1;
-        tab[2][tid] = m2;
+        tab[1][tid] = r1;
+        tab[2][tid] = r2;
     }
     __syncthreads();
     const int q = tid & 7, g = tid >> 3;
@@ -775,21 +859,43 @@ __global__ __launch_bounds__(HNM_T) void head_bwd_kernel(const float* __restrict
 #pragma unroll
     for (int e = 0; e < 4; ++e) { inv[e] = tab[0][q * 4 + e]; m1[e] = tab[1][q * 4 + e]; m2[e] = tab[2][q * 4 + e]; }
     if (q * 4 < ld_a) {
-        for (int pass = 0; pass < HNM_CHUNK / 32; ++pass) {
+        constexpr int NP = HNM_CHUNK / 32;
+        float4 avv[NP], yvv[NP];
+        float wv[NP], pv[NP][4];
+        int lv[NP];
+#pragma unroll
+        for (int pass = 0; pass < NP; ++pass) {      // every load of the chunk in flight together (probs of unweighted cells too)
+            bool in;
+            const long long i = chunk_cell(cm, chunk, pass * 32 + g, in);
+            avv[pass] = yvv[pass] = make_float4(0.f, 0.f, 0.f, 0.f);
+            wv[pass] = 0.f;
+            lv[pass] = -1;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) pv[pass][e] = 0.f;
+            if (in) {
+                avv[pass] = *reinterpret_cast<const float4*>(a + i * ld_a + q * 4);
+                yvv[pass] = *reinterpret_cast<const float4*>(logits + i * ld_l + q * 4);
+                wv[pass] = weight[i];
+                lv[pass] = label_at(labels, label_bytes, i);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) if (q * 4 + e < C) pv[pass][e] = probs[i * C + q * 4 + e];
+            }
+        }
+#pragma unroll
+        for (int pass = 0; pass < NP; ++pass) {
             bool in;
             const long long i = chunk_cell(cm, chunk, pass * 32 + g, in);
             if (!in) continue;
-            const float4 av = *reinterpret_cast<const float4*>(a + i * ld_a + q * 4);
-            const float4 yv = *reinterpret_cast<const float4*>(logits + i * ld_l + q * 4);
+            const float4 av = avv[pass], yv = yvv[pass];
             const float ae[4] = {av.x, av.y, av.z, av.w}, ye[4] = {yv.x, yv.y, yv.z, yv.w};
-            const float w = weight[i];
-            const int lab = w != 0.f ? label_at(labels, label_bytes, i) : -1;
+            const float w = wv[pass];
+            const int lab = lv[pass];
             TZ o[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int c = q * 4 + e;
                 float dy = 0.f;
-                if (w != 0.f && c < C) dy = S * w * (probs[i * C + c] - (lab == c ? 1.f : 0.f));
+                if (w != 0.f && c < C) dy = S * w * (pv[pass][e] - (lab == c ? 1.f : 0.f));
                 float d = inv[e] * __builtin_fmaf(-ye[e], m2[e], dy - m1[e]);
                 if (!(ae[e] > 0.f) || c >= C) d = 0.f;
                 sb[e] += d;
@@ -873,14 +979,14 @@ extern "C" int cutie_softmax_ce_fwd(const void* logits, int ld, int dtype, const
 static inline int64_t hnm_chunks(int64_t n_cells) { return n_cells > 0 ? cutie::cdiv(n_cells, HNM_CHUNK) : 1; }
 
 extern "C" size_t cutie_hnm_workspace_bytes(int64_t n_cells) {
-    return (size_t)(HNM_INT_HEAD + 3 * hnm_chunks(n_cells)) * 4 + 64;
+    return (size_t)(HNM_INT_HEAD + HNM_PER_CHUNK * hnm_chunks(n_cells)) * 4 + 64;
 }
 
 // the six launches of the select over a zero-filled work area `ws` (16-byte aligned, hnm_ws layout)
 static int hnm_launch(const float* ce, const int32_t* labels, int64_t n_cells, int ratio, float* weight, float* loss_out,
                       void* ws, hipStream_t stream) {
     const int chunks = (int)hnm_chunks(n_cells);
-    CUTIE_CHECK_HIP(hipMemsetAsync(ws, 0, (size_t)(HNM_INT_HEAD + 3 * chunks) * 4, stream));
+    CUTIE_CHECK_HIP(hipMemsetAsync(ws, 0, (size_t)(HNM_INT_HEAD + HNM_PER_CHUNK * chunks) * 4, stream));
     const dim3 g(chunks), t(HNM_T);
     const CellMap cm = {(long long)n_cells, chunks};      // one "sample" of n_cells cells
     const HeadRed none = {nullptr, nullptr, 0, 0, nullptr, nullptr};
@@ -889,7 +995,7 @@ static int hnm_launch(const float* ce, const int32_t* labels, int64_t n_cells, i
     hipLaunchKernelGGL(hnm_hist_kernel<2>, g, t, 0, stream, ce, (const void*)labels, 4, cm, chunks, ratio, ws);
     hipLaunchKernelGGL(hnm_tie_kernel, g, t, 0, stream, ce, (const void*)labels, 4, cm, chunks, ratio, ws);
     hipLaunchKernelGGL(hnm_weight_kernel, g, t, 0, stream, ce, (const void*)labels, 4, cm, chunks, ratio, ws, weight, none);
-    hipLaunchKernelGGL(hnm_final_kernel, dim3(1), dim3(64), 0, stream, chunks, ratio, ws, loss_out);
+    hipLaunchKernelGGL(hnm_final_kernel, dim3(1), dim3(HNM_T), 0, stream, chunks, ratio, ws, loss_out);
     CUTIE_CHECK_LAUNCH();
     return CUTIE_OK;
 }
@@ -911,12 +1017,12 @@ extern "C" int cutie_hnm_weights(const float* ce, const int32_t* labels, int64_t
 
 // ---------------------------------------------------------------------------------------------
 // cutie_hnm_weights for callers that cannot allocate (HIP graph capture, serving loops): the work area of the
-// select - three histograms, eight counters and three words per 1024-cell chunk - lives in a device array of the
+// select - three histograms, eight counters and three words per 256-cell chunk - lives in a device array of the
 // code object instead of a caller workspace.  Each GPU the library runs on holds its own copy at its own address
 // until the process ends; the host only ever uses the address hipGetSymbolAddress returned for the CURRENT device
 // (the array's name is a host-side stand-in, never a device pointer).
 constexpr int64_t HNM_STATIC_MAX_CELLS = (int64_t)CUTIE_HNM_STATIC_MAX_CELLS;
-constexpr size_t HNM_STATIC_BYTES = (size_t)(HNM_INT_HEAD + 3 * (HNM_STATIC_MAX_CELLS / HNM_CHUNK)) * 4;
+constexpr size_t HNM_STATIC_BYTES = (size_t)(HNM_INT_HEAD + HNM_PER_CHUNK * (HNM_STATIC_MAX_CELLS / HNM_CHUNK)) * 4;
 static __device__ __align__(256) unsigned char g_hnm_scratch[HNM_STATIC_BYTES];
 
 namespace {
@@ -960,7 +1066,7 @@ extern "C" int cutie_hnm_weights_static(const float* ce, const int32_t* labels, 
 extern "C" int cutie_head_tiles(int HW) { return HW < 1 ? 1 : (HW + HEAD_TILE - 1) / HEAD_TILE; }
 extern "C" int cutie_head_chunks(int HW) { return HW < 1 ? 1 : (HW + HNM_CHUNK - 1) / HNM_CHUNK; }
 extern "C" size_t cutie_head_workspace_bytes(int B, int HW) {
-    return (size_t)(HNM_INT_HEAD + 3 * (int64_t)(B < 1 ? 1 : B) * cutie_head_chunks(HW)) * 4 + 64;
+    return (size_t)(HNM_INT_HEAD + HNM_PER_CHUNK * (int64_t)(B < 1 ? 1 : B) * cutie_head_chunks(HW)) * 4 + 64;
 }
 
 static int head_check(const char* name, int B, int HW, int C, int ld_a, int ld_l, const void* a, const void* logits) {
@@ -992,15 +1098,15 @@ extern "C" int cutie_head_fwd(const void* x, int ld_x, int dtype, int B, int HW,
             cutie::set_error("head_fwd: workspace %zu < %zu", workspace_bytes, need);
             return CUTIE_E_WORKSPACE;
         }
-        ws = (void*)(((uintptr_t)workspace + 15) & ~(uintptr_t)15);
-        CUTIE_CHECK_HIP(hipMemsetAsync(ws, 0, (size_t)(HNM_INT_HEAD + 3 * (int64_t)B * cps) * 4, stream));
+        ws = (void*)(((uintptr_t)workspace + 15) & ~(uintptr_t)15);      // cleared by head_conv_kernel's workgroups
     }
+    const int ws_words = labels ? HNM_INT_HEAD : 0;      // the per-chunk words are all STORED before they are read
     if (dtype == CUTIE_BF16) {
         hipLaunchKernelGGL(head_conv_kernel<CUTIE_BF16>, dim3(tiles, B), dim3(256), 0, stream, (const bf16_t*)x, ld_x, HW, cin,
-                           w_hwio, bias, C, a, ld_a, stats, stats_tiles);
+                           w_hwio, bias, C, a, ld_a, stats, stats_tiles, (int*)ws, ws_words);
     } else {
         hipLaunchKernelGGL(head_conv_kernel<CUTIE_F16>, dim3(tiles, B), dim3(256), 0, stream, (const f16_t*)x, ld_x, HW, cin,
-                           w_hwio, bias, C, a, ld_a, stats, stats_tiles);
+                           w_hwio, bias, C, a, ld_a, stats, stats_tiles, (int*)ws, ws_words);
     }
     CUTIE_CHECK_LAUNCH();
     const CellMap cm = {(long long)HW, cps};

@@ -237,8 +237,9 @@ class Engine(object):
         P.weight = torch.zeros(N, dtype=torch.float32, device=dev)
         P.loss = torch.zeros(4, dtype=torch.float32, device=dev)
         P.zero_labels = torch.zeros(N, dtype=torch.int32, device=dev)
-        P.grid = torch.zeros((B, H, W), dtype=torch.int32, device=dev)
-        P.labels = torch.zeros((B, H, W), dtype=torch.int32, device=dev)
+        P.grid_buf = torch.zeros((B, H, W), dtype=torch.int32, device=dev)
+        P.labels_buf = torch.zeros((B, H, W), dtype=torch.int32, device=dev)
+        P.grid, P.labels = P.grid_buf, P.labels_buf      # forward() points them at the caller's device tensors where it can
         P.ps = torch.zeros((B, H * W), dtype=torch.int32, device=dev) if Hi else None
         P.bwd_ready = False
         self._plans[key] = P
@@ -282,7 +283,7 @@ class Engine(object):
             fusable = n.name != net.loss_logits_name and self.dt != F32
             rows = max(ct, t) if fusable else t
             if n is P.head:
-                rows = ops.head_chunks(hs * ws)          # cutie_head_bwd: one row per (sample, 1024-cell chunk)
+                rows = ops.head_chunks(hs * ws)          # cutie_head_bwd: one row per (sample, 256-cell chunk)
             P.dbpart[n.name] = torch.zeros((B * rows, n.channels), dtype=torch.float32, device=dev)
             # tagged granules of that launch's tile rendezvous (word 0: timeouts); zeroed once, then the library's
             P.sync[n.name] = torch.zeros(ops.conv_sync_bytes(B, ct, n.channels) // 4, dtype=torch.int32, device=dev)
@@ -434,9 +435,22 @@ class Engine(object):
             if int(img.shape[2]) != W or int(img.shape[0]) != B:
                 raise CutieError("data_image %s does not match grid %s (width = cols)" % (tuple(img.shape), (B, H, W)))
         P = self._plan(B, H, W, Hi)
-        P.grid.copy_(g.to(torch.int32), non_blocking=True)
+        # Device tensors of the right type are used IN PLACE, not copied (cutie_grid_build's int32 grid and int8 label grid
+        # go straight into the kernels): the caller must leave them alone until the step that reads them is done.
+        if g.is_cuda and g.device == self.dev and g.dtype == torch.int32 and g.is_contiguous():
+            P.grid = g
+        else:
+            P.grid = P.grid_buf
+            P.grid.copy_(g.to(torch.int32), non_blocking=True)
         if labels is not None:
-            P.labels.copy_(torch.as_tensor(labels).to(torch.int32).reshape(B, H, W), non_blocking=True)
+            lab = torch.as_tensor(labels).reshape(B, H, W)
+            in_place = lab.is_cuda and lab.device == self.dev and lab.is_contiguous() and (
+                lab.dtype == torch.int32 or (lab.dtype == torch.int8 and P.head is not None))     # the head kernels take int8
+            if in_place:
+                P.labels = lab
+            else:
+                P.labels = P.labels_buf
+                P.labels.copy_(lab.to(torch.int32), non_blocking=True)
         if Hi:
             P.bufs["data_image"][..., :3].copy_(img.to(self.dev))
             P.ps.copy_(torch.as_tensor(ps_1d_indices).to(torch.int32).reshape(B, H * W))

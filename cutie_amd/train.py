@@ -21,7 +21,7 @@ from .parallel import GradBuckets, dist_info
 class Trainer(object):
     def __init__(self, engine, learning_rate=1e-4, clip_norm=10.0, beta1=0.9, beta2=0.999, epsilon=1e-8,
                  lr_decay_step=13000, lr_decay_factor=0.1, n_buckets=4, check_inputs=False,
-                 scale_growth_interval=1000):
+                 scale_growth_interval=1000, gc_freeze=True):
         self.eng = engine
         self.lr = float(learning_rate)
         self.clip, self.b1, self.b2, self.eps = float(clip_norm), beta1, beta2, epsilon
@@ -29,6 +29,13 @@ class Trainer(object):
         self.iter = 0          # the reference's `iter` (drives lr decay)
         self.t = 0             # Adam's step count
         self.check_inputs = check_inputs
+        # After the first step everything long-lived exists (torch, the engine's plans, the descriptor tables): move it out
+        # of the garbage collector's reach (gc.freeze).  A full collection over that object graph takes ~39 ms of HOST time
+        # on the MI355X box (tools/step_trace.py) - five device steps; it is absorbed while the host runs ahead of the
+        # device queue and stalls the device when it does not (the "38 ms start-up step" of rounds 1 and 2: a gen-2 pass
+        # in a step that the caller synchronised).  Frozen objects are never scanned again; new garbage is collected as before.
+        self.gc_freeze = bool(gc_freeze)
+        self._frozen = False
         self.scale_growth_interval = int(scale_growth_interval)
         self.m = torch.zeros_like(engine.params_flat)
         self.v = torch.zeros_like(engine.params_flat)
@@ -73,6 +80,11 @@ class Trainer(object):
         if self.check_inputs:
             eng.check_inputs(P)            # late tiles of the whole step, backward included (the device skipped it already)
         self.iter += 1
+        if self.gc_freeze and not self._frozen:
+            import gc
+            gc.collect()
+            gc.freeze()
+            self._frozen = True
         if not fetch:
             return None
         ml, rg, tl = eng.losses(P)

@@ -346,7 +346,7 @@ int cutie_hnm_weights(const float* ce, const int32_t* labels, int64_t n_cells, i
 /* cutie_hnm_weights without a workspace argument and without any allocation.  No counterpart in the
  * reference: it is for callers that cannot allocate device memory - code under HIP graph capture, tight
  * serving loops, harnesses that forbid hipMalloc.  Same kernels, same results bit for bit; the select's work
- * area (histograms, counters, per-chunk words: 69 KB) is a device array of the library's code object, one copy
+ * area (histograms, counters, per-chunk words: 348 KB) is a device array of the library's code object, one copy
  * per GPU for the life of the process.  n_cells <= CUTIE_HNM_STATIC_MAX_CELLS, else CUTIE_E_ARG.  The current
  * device must be the one the pointers and the stream belong to.  Every call on a GPU shares that GPU's array
  * (each call clears what it uses first): calls that overlap on one GPU - two streams, two threads - race.
