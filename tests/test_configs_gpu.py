@@ -75,7 +75,7 @@ def test_cutie2_aspp_full_shape_128x64_vocab_28790():
         d = logits2.double().cpu() - r
         err_l2, err_max = float(d.norm() / r.norm()), float(d.abs().max() / r.abs().max())
         print("CUTIE2-ASPP 128x64 V=28790 %s: logits rel-L2 %.2e, max-norm %.2e" % (dtype, err_l2, err_max))
-        assert err_l2 < tol and err_max < (tol if dtype == "f32" else 2 * tol)
+        assert err_l2 < tol and err_max < tol      # north_star's bound in both norms (f16 measured 1.9e-2 / 1.8e-2)
         if dtype == "f32":
             agree = float((logits2.argmax(-1).cpu() == r.argmax(-1)).double().mean())
             assert agree >= 0.999

@@ -127,6 +127,10 @@ def test_cutie_aspp_forward_backward_parity(oracle_run, dtype):
                 for k in conv_names)
     total = sum(masks[k].numel() for k in conv_names)
     print(dtype, "ReLU pattern: %d of %d activations differ from the f64 oracle's" % (flips, total))
+    # a pre-activation within rounding of zero may fall on either side; anything beyond that share would be a wrong
+    # pattern (e.g. one carried wrongly inside y): f32 measured 46 of 25.8 M = 1.8e-6, 16-bit paths ~1e-3 (their
+    # pre-activations carry ~5e-3 relative error, and ~0.1 % of them lie that close to zero)
+    assert flips <= {"f32": 1e-5, "f16": 3e-3, "bf16": 2e-2}[dtype] * total, (flips, total)
     o = co.loss_and_grads(r["params"], r["grid"], r["labels"], masks=masks, cell_weights=P.weight.double().cpu())
     assert abs(ml - float(r["out"]["model_loss"])) < tol * abs(float(r["out"]["model_loss"]))
     assert abs(rg - float(o["reg_loss"])) < 1e-4 * abs(float(o["reg_loss"]))
