@@ -117,29 +117,109 @@ class ConvTimer(object):
 
 
 def kernel_source_sha():
-    """sha256 over the conv kernel sources: a PMC profile only describes the kernels it was taken with"""
+    """sha256 over the kernel sources: a PMC profile only describes the kernels it was taken with"""
     import hashlib
     h = hashlib.sha256()
-    for f in ("conv_wide.hip", "conv_common.h", "conv_mfma.hip", "common.h"):
+    for f in ("conv_wide.hip", "conv_common.h", "conv_mfma.hip", "common.h", "embed.hip", "loss.hip"):
         with open(os.path.join(REPO, "cutie_amd", "csrc", f), "rb") as fh:
             h.update(fh.read())
     return h.hexdigest()[:16]
+
+
+def _pmc_profile():
+    import glob
+    files = sorted(glob.glob(os.path.join(REPO, "profiles", "r*_pmc.json")))
+    if not files:
+        return None, None, "no profiles/*_pmc.json"
+    with open(files[-1]) as f:
+        prof = json.load(f)
+    rel = os.path.relpath(files[-1], REPO)
+    if prof.get("source_sha") != kernel_source_sha():
+        return None, rel, "%s was taken with other kernel sources (source_sha %s != %s): not reported" % (
+            rel, prof.get("source_sha"), kernel_source_sha())
+    return prof, rel, None
+
+
+class CallTimer(object):
+    """HIP events around the HBM-bound calls of the path north_star names - the embedding gather and its scatter-add, the
+    softmax-CE head forward and backward - on the instrumented steps, in place (inside real steps: their operands are as
+    cold as they are in training, not re-read from a warm cache by a micro-benchmark loop)."""
+    # call -> (kernels of the call as the profile names them, algorithmic bytes per cell by SURVEY.md 8d for 16-bit activations)
+    CALLS = {
+        "embed_fwd": (("embed_fwd_kernel",), lambda E, C: 4 + 2 * E * 2,
+                      "gather: id + table row + stored row (SURVEY.md 8d: 4 + 2*E*s)"),
+        "embed_bwd": (("embed_bwd_kernel", "embed_bwd_fold_kernel"), lambda E, C: 4 + E * 2 + E * 4,
+                      "scatter-add: id + gradient row read + f32 row added (SURVEY.md 8d: 4 + E*s + E*4; rows of one id are "
+                      "summed per workgroup first, so far fewer bytes reach the table)"),
+        "head_fwd": (("head_conv_kernel", "head_norm_ce_kernel"), lambda E, C: 64 * 2 + 3 * C * 4 + 4 + 4 + C * 4,
+                     "logits layer (64 x C MFMA) + instance norm + softmax + CE: x row read, a written and read, logits, probs, "
+                     "label, ce (SURVEY.md 8d counts C*4 read + 4 + 4 + C*4 probs for the loss alone)"),
+        "head_bwd": (("hnm_hist_kernel", "hnm_tie_kernel", "hnm_weight_kernel", "head_bwd_kernel"),
+                     lambda E, C: 3 * (4 + 1) + (4 + 1 + 4) + 3 * C * 4 + 4 + 64 * 2,
+                     "hard-negative select (three passes over ce + labels), weights, d(loss)/d(logits) and the logits layer's "
+                     "norm + ReLU gradient: a, logits, probs read, dz row written"),
+    }
+
+    def __init__(self, ops):
+        self.ops, self.enabled = ops, False
+        self.ms = {k: [] for k in self.CALLS}
+        self.events = {k: [] for k in self.CALLS}
+        for name in self.CALLS:
+            setattr(ops, name, self._wrap(name, getattr(ops, name)))
+
+    def _wrap(self, name, fn):
+        def call(*a, **kw):
+            if not self.enabled:
+                return fn(*a, **kw)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            r = fn(*a, **kw)
+            e1.record()
+            self.events[name].append((e0, e1))
+            return r
+        return call
+
+    def report(self, n_cells, E, C):
+        prof, rel, why = _pmc_profile()
+        out = []
+        for name, (kernels, per_cell, what) in self.CALLS.items():
+            ev = self.events[name]
+            if not ev:
+                continue
+            ms = sum(a.elapsed_time(b) for a, b in ev) / len(ev)
+            alg = per_cell(E, C) * n_cells
+            e = {"call": name, "what": what, "kernels": list(kernels), "ms": round(ms, 4), "bytes_algorithmic": int(alg),
+                 "GBps_algorithmic": round(alg / (ms * 1e-3) / 1e9, 1)}
+            pmc = None
+            if prof is not None:
+                pmc = 0
+                for kn in kernels:
+                    hit = [v for k, v in prof["kernels"].items() if kn in k]
+                    if not hit:
+                        pmc = None
+                        break
+                    # gfx950 tallies a 16-byte-per-lane read stream at half its bytes (MI355X_MICROARCH.md, HBM): the kernels
+                    # that read float4 / 8 x f16 per lane take the doubled FETCH_SIZE, the 4- and 8-byte readers the raw one
+                    wide = kn.startswith(("embed_fwd", "head_"))
+                    pmc += sum(h["hbm_bytes_per_launch" if wide else "hbm_bytes_raw"] for h in hit)
+            e["bytes_pmc"] = pmc
+            if pmc is not None:
+                e["GBps"] = round(pmc / (ms * 1e-3) / 1e9, 1)
+                e["frac_of_8TBps"] = round(pmc / (ms * 1e-3) / 8e12, 4)
+            else:
+                e["GBps"], e["frac_of_8TBps"] = None, None
+                e["bytes_pmc_source"] = why
+            out.append(e)
+        return out, rel
 
 
 def pmc_traffic(dtype):
     """HBM bytes per conv_wide launch from the newest committed PMC profile (PMC passes cannot run inside the timed
     bench).  Reported only when that profile was taken with the kernel sources of this tree (its `source_sha`);
     otherwise null, with the reason."""
-    import glob
-    files = sorted(glob.glob(os.path.join(REPO, "profiles", "r*_pmc.json")))
-    if not files:
-        return None, "no profiles/*_pmc.json"
-    with open(files[-1]) as f:
-        prof = json.load(f)
-    rel = os.path.relpath(files[-1], REPO)
-    if prof.get("source_sha") != kernel_source_sha():
-        return None, "%s was taken with other kernel sources (source_sha %s != %s): not reported" % (
-            rel, prof.get("source_sha"), kernel_source_sha())
+    prof, rel, why = _pmc_profile()
+    if prof is None:
+        return None, why
     # one kernel instance per epilogue mode (plain / norm sums / backward rendezvous / forward rendezvous): launch-weighted mean
     code = {"bf16": 1, "f16": 2}.get(dtype, -1)
     ks = [v for name, v in prof["kernels"].items() if name.startswith("conv_wide_kernel<%d, 256," % code)]
@@ -227,6 +307,7 @@ def main():
     packed = make_documents(B, C, seed=1234 + 1000 * rank)
     tok = {k: torch.from_numpy(v).to(dev) for k, v in packed.items()}
     timer = ConvTimer(ops)
+    calls = CallTimer(ops)
 
     def step():
         g = ops.grid_build(tok["tok_box"], tok["tok_id"], tok["tok_ecid"], tok["doc_extent"], tok["doc_off"], H, W, 1)
@@ -251,6 +332,7 @@ def main():
     overlap = eng.overlap_wgrad
     for k in range(args.steps):
         timer.enabled = (not args.no_kernel_timing) and k % ConvTimer.EVERY == 0
+        calls.enabled = timer.enabled
         # an instrumented step keeps the weight gradients on the launch stream: the events must see one
         # kernel at a time (beside a weight gradient a conv launch shares the chip and reads longer)
         eng.overlap_wgrad = overlap and not timer.enabled
@@ -258,6 +340,7 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     timer.enabled = False
+    calls.enabled = False
     eng.overlap_wgrad = overlap
     if use_dist:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
@@ -297,6 +380,8 @@ def main():
                                    ConvTimer.EVERY, args.steps,
                                    ", run on one stream (the others run the weight gradients on a second stream)" if overlap else ""),
                                "share_of_step": round(ms / max(1, -(-args.steps // ConvTimer.EVERY)) / (1e3 * dt / args.steps), 4)}
+            # the HBM-bound kernels north_star names (gather, loss): event time inside real steps, bytes from the PMC profile
+            out["roofline_hbm"], _ = calls.report(B * H * W, E, C)
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(C, V, E, H, W, packed)
     if args.dtype in ("f16", "bf16") and not args.no_alt:

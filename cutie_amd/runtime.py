@@ -617,10 +617,14 @@ class Engine(object):
             if self._side is None:
                 self._side = torch.cuda.Stream(device=self.dev)
             side = self._side
-        # data parallel keeps the layer-by-layer calls: a finished prefix of the gradient buffer goes to its all-reduce while
-        # earlier layers compute, and batches of 3-5 layers measured 1.8-3 % SLOWER than layer by layer on one GPU
-        defer = self.wgrad_batch and side is None and on_ready is None
+        # The weight gradients go out as batched calls (cutie_conv_wgrad_batched).  Data parallel (on_ready): TWO of them -
+        # the layers of the first half of the conv range (the decoder and the ASPP side: the front of the flat buffer) as
+        # soon as their dz exist, so that their buckets' all-reduce runs under the rest of backward, the others at the end.
+        # (Round 2 kept layer-by-layer calls there because batches of 3-5 layers were 1.8-3 % slower than single calls;
+        # two batches of ~7 fill the chip like the one of 14.)
+        defer = self.wgrad_batch and side is None
         pending = []
+        pending_elems = [0]
 
         def flush():
             if not pending:
@@ -640,7 +644,11 @@ class Engine(object):
                     self._wgrad_bws = None
                     self._wgrad_bws = torch.empty(need, dtype=torch.uint8, device=self.dev)
                 ops.conv_wgrad_batched(arr, dtc, self._wgrad_bws)
+            if on_ready is not None:
+                off, cnt, _ = self.offsets[pending[-1].name + "/weights"]
+                on_ready(_pad(off + cnt, 64))      # everything up to the last layer of the batch is final
             del pending[:]
+            pending_elems[0] = 0
 
         for n in reversed(net.nodes):
             if n.op == "conv":
@@ -665,6 +673,9 @@ class Engine(object):
                     # until the end of the pass: all layers' weight gradients go out as ONE call at the end (fewer K
                     # splits, one reduction launch - cutie_conv_wgrad_batched)
                     pending.append(n)
+                    pending_elems[0] += self.offsets[n.name + "/weights"][1]
+                    if on_ready is not None and pending_elems[0] >= self.n_conv_w // 2:
+                        flush()
                     continue
                 with torch.cuda.stream(side if side is not None else main):
                     ops.conv_wgrad(P.view(src.name, a["cin"]), a["cin"], P.dz[n.name][..., :n.channels], n.channels,
