@@ -17,6 +17,7 @@ struct Config {
     bool fuse_norm_bwd;   // CUTIE_FUSE_NORM_BWD=0: data gradient and norm-backward sums as two passes
     bool conv_lpt;        // CUTIE_CONV_LPT=0: conv_wide tiles in row-major order
     bool rendezvous;      // CUTIE_RENDEZVOUS=0: cutie_conv_dgrad_in_bwd always as data gradient + cutie_in_bwd_apply
+    bool conv_ring;       // CUTIE_CONV_RING=1 in a -DCW_WITH_RING variant build: conv_wide's four-stage ring (measured slower)
 };
 const Config& config();
 

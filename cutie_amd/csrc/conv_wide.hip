@@ -41,6 +41,21 @@ template <int BN> struct Shape {
     static constexpr int LDS = (CW_B0 + 2 * BBUF > TAB + 2 * BN * 4) ? CW_B0 + 2 * BBUF : TAB + 2 * BN * 4;
 };
 
+// The four-stage ring of 32-channel K steps (conv_wide_kernel<..., RING = true>): a stage holds the A tile of a step
+// (256 pixel rows x 64 B) and its B tile (BN weight rows x 64 B); 4 x 32 KB at BN = 256.  Rows are 64 B = four 16-byte
+// chunks; chunk c of row r sits at chunk position c ^ rswz(r), which keeps the 16 lanes of every ds_read_b128 lane group
+// (MI355X_MICROARCH.md, LDS) on 16 different 16-byte bank groups.
+constexpr int RG_ABUF = 16384;
+template <int BN> struct Ring {
+    static constexpr int BBUF = BN * 64;
+    static constexpr int STAGE = RG_ABUF + BBUF;
+    static constexpr int NBP = BN / 128;        // 1-KB pieces of the B tile per wave and step
+    static constexpr int NP = 2 + NBP;          // pieces per wave and step (A: always 2)
+    static_assert(BN % 128 == 0, "the ring wants whole pieces per wave");
+    static_assert(4 * STAGE <= Shape<BN>::LDS, "ring does not fit the kernel's LDS grant");
+};
+__device__ __forceinline__ int rswz(int row) { return (0x1320 >> (((row >> 2) & 3) * 4)) & 3; }      // {0, 2, 3, 1}[(row >> 2) & 3]
+
 __device__ __forceinline__ unsigned short u16_of(const uint4& u, int e) {      // e-th 16-bit element of a 16-byte piece
     const unsigned c = e < 2 ? u.x : (e < 4 ? u.y : (e < 6 ? u.z : u.w));
     return (unsigned short)((e & 1) ? (c >> 16) : (c & 0xffffu));
@@ -471,7 +486,7 @@ __device__ __forceinline__ void conv_wide_epilogue(const ConvParams& p, float4_t
 }
 
 // MODE: the epilogue (conv_wide_epilogue) - one kernel instance per mode, so that each allocates registers for its own path
-template <int DT, int BN, int MODE, bool FY, bool RELU>
+template <int DT, int BN, int MODE, bool FY, bool RELU, bool RING = false>
 __global__ __launch_bounds__(CW_NT) void conv_wide_kernel(ConvParams p) {
     typedef Shape<BN> S;
     constexpr int MB = S::MB, NB = S::NB, NP = S::NP;
@@ -539,6 +554,154 @@ __global__ __launch_bounds__(CW_NT) void conv_wide_kernel(ConvParams p) {
         const int c16 = ((kk * 4 + lg) ^ ((li >> 1) & 7)) * 16;
         a_rd[kk] = (wm * (MB * 16) + li) * 128 + c16;
         b_rd[kk] = (wn * 64 + li) * 128 + c16;
+    }
+    if constexpr (RING) {
+        // ---- Four-stage ring, one K step = (tap, 32 input channels) = MB x 4 MFMAs a wave.  While step s computes from
+        // registers, the fragments of step s+1 are read out of their (already complete) stage and the pieces of step
+        // s+3 are sent on their way, so the barrier that closes a step only orders buffer reuse: nothing waits for LDS
+        // right behind it (the two-stage loop below reads a step's first fragments AFTER its barrier).  Round-3 experiment:
+        // bit-identical results, no spills, and 5 % SLOWER per launch (194 -> 204 us, whole step 7.66 -> 7.93 ms, A/B on one
+        // box, tools/gpu_ring_ab.sh) - the round trip behind the barrier is not what the loop waits for.  Kept for
+        // variant builds (-DCW_WITH_RING, CUTIE_CONV_RING=1); never instantiated in the shipped library.
+        typedef Ring<BN> R;
+        constexpr int NBP = R::NBP, NPR = R::NP;
+        int ra_h[2], ra_w[2], ra_c16[2], rb_row[NBP], rb_c16[NBP];
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int r = (wave * 2 + k) * 16 + (lane >> 2);        // tile pixel 0..255
+            const int mb = r >> 4;
+            ra_h[k] = h0 + mb / TCB;
+            ra_w[k] = w0 + (mb % TCB) * 16 + (r & 15);
+            ra_c16[k] = ((lane & 3) ^ rswz(r)) * 16;
+        }
+#pragma unroll
+        for (int k = 0; k < NBP; ++k) {
+            const int r = (wave * NBP + k) * 16 + (lane >> 2);      // weight row 0..BN-1
+            rb_row[k] = n0 + r;
+            rb_c16[k] = ((lane & 3) ^ rswz(r)) * 16;
+        }
+        const int rc16 = (lg ^ rswz(li)) * 16;
+        const int ra_rd = (wm * (MB * 16) + li) * 64 + rc16;          // + m * 1024 per 16-pixel block
+        const int rb_rd = RG_ABUF + (wn * 64 + li) * 64 + rc16;       // + n * 1024 per 16-channel block
+        uint4 fb0[4], fa0[MB], fb1[4], fa1[MB];                       // the fragments of the step in hand / of the next one
+
+        for (int s = 0; s < p.nseg; ++s) {
+            const Seg g = p.seg[s];
+            const int ncc = g.cin >> 5;
+            unsigned live = 0;
+            for (int i = 0; i < g.kh; ++i) {
+                const int sy = g.sgn * (i - g.kh / 2) * g.dil;
+                if (h0 + sy + TR - 1 < 0 || h0 + sy >= H) continue;
+                for (int j = 0; j < g.kw; ++j) {
+                    const int sx = g.sgn * (j - g.kw / 2) * g.dil;
+                    if (w0 + sx + TC - 1 < 0 || w0 + sx >= W) continue;
+                    live |= 1u << (i * g.kw + j);
+                }
+            }
+            live = __builtin_amdgcn_readfirstlane(live);
+            if (live == 0u) continue;
+            const int nsteps = __builtin_popcount(live) * ncc;
+
+            const long long xbytes = ((long long)(H * W - 1) * g.ld_x + g.cin) * 2;
+            const u32x4s_t rsrc_x = make_rsrc(g.x + (long long)b * H * W * g.ld_x * 2, (unsigned)xbytes);
+            const long long wbytes = ((long long)(g.kh * g.kw - 1) * g.w_tap_stride + (long long)n_out * g.cin) * 2;
+            const u32x4s_t rsrc_w = make_rsrc(g.w, (unsigned)wbytes);
+            int a_base[2];
+            unsigned b_base[NBP];
+#pragma unroll
+            for (int k = 0; k < 2; ++k) a_base[k] = (ra_h[k] * W + ra_w[k]) * g.ld_x * 2 + ra_c16[k];
+#pragma unroll
+            for (int k = 0; k < NBP; ++k) b_base[k] = rb_row[k] < n_out ? (unsigned)(rb_row[k] * g.cin * 2 + rb_c16[k]) : BUF_OOB;
+
+            // the step whose pieces go out next: taps innermost (consecutive steps read the same 64-byte channel chunk of
+            // overlapping pixels: L2), then the next 32 channels; beyond the last step the pieces are zero fills
+            unsigned irest = live;
+            int icc = 0, issued = 0, da = 0, sy = 0, sx = 0;
+            unsigned db = 0;
+            bool ivalid = false;
+            auto advance = [&]() {
+                ivalid = issued < nsteps;
+                ++issued;
+                if (!ivalid) return;
+                if (irest == 0u) { irest = live; ++icc; }
+                const int tap = __builtin_ctz(irest);
+                irest &= irest - 1;
+                const int i = tap / g.kw, j = tap - i * g.kw;
+                sy = g.sgn * (i - g.kh / 2) * g.dil;
+                sx = g.sgn * (j - g.kw / 2) * g.dil;
+                da = ((sy * W + sx) * g.ld_x + icc * 32) * 2;
+                db = (unsigned)(((long long)tap * g.w_tap_stride + icc * 32) * 2);
+            };
+            auto issue_piece = [&](int piece, int stage) {
+                const unsigned dst = lds0 + stage * R::STAGE;
+                if (piece < 2) {
+                    const int k = piece;
+                    const bool ok = ivalid && (unsigned)(ra_h[k] + sy) < (unsigned)H && (unsigned)(ra_w[k] + sx) < (unsigned)W;
+                    glds16(rsrc_x, dst + (wave * 2 + k) * 1024, ok ? (unsigned)(a_base[k] + da) : BUF_OOB);
+                } else {
+                    const int k = piece - 2;
+                    glds16(rsrc_w, dst + RG_ABUF + (wave * NBP + k) * 1024, ivalid ? b_base[k] + db : BUF_OOB);
+                }
+            };
+            auto load_frags = [&](int stage, uint4 (&fb)[4], uint4 (&fa)[MB]) {
+                const char* St = smem + stage * R::STAGE;
+#pragma unroll
+                for (int n = 0; n < 4; ++n) fb[n] = *reinterpret_cast<const uint4*>(St + rb_rd + n * 1024);
+#pragma unroll
+                for (int m = 0; m < MB; ++m) fa[m] = *reinterpret_cast<const uint4*>(St + ra_rd + m * 1024);
+            };
+            // one step: MB groups of 4 MFMAs on (cb, ca); between the groups the next step's fragments are read into
+            // (nb, na) and the pieces of the step three ahead are issued
+            auto do_step = [&](int st, uint4 (&cb)[4], uint4 (&ca)[MB], uint4 (&nb)[4], uint4 (&na)[MB]) {
+                const char* Sn = smem + ((st + 1) & 3) * R::STAGE;
+                const int sti = (st + 3) & 3;
+                constexpr int G0 = MB >= 8 ? 2 : 1;      // first group that carries a piece
+#pragma unroll
+                for (int m = 0; m < MB; ++m) {
+                    if (m < 2) {
+                        nb[2 * m] = *reinterpret_cast<const uint4*>(Sn + rb_rd + (2 * m) * 1024);
+                        nb[2 * m + 1] = *reinterpret_cast<const uint4*>(Sn + rb_rd + (2 * m + 1) * 1024);
+                    }
+                    na[m] = *reinterpret_cast<const uint4*>(Sn + ra_rd + m * 1024);
+#pragma unroll
+                    for (int q = 0; q < NPR; ++q)
+                        if (G0 + q == m || (G0 + q >= MB && m == MB - 1)) issue_piece(q, sti);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int n = 0; n < 4; ++n) mma_frag<DT>(cb[n], ca[m], acc[m][n]);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            };
+
+            // ---- prologue: steps 0..2 on their way, steps 0 and 1 complete, the fragments of step 0 in registers
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the previous segment's trailing zero fills
+            __builtin_amdgcn_s_barrier();                         // ... and its last fragment reads
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                advance();
+#pragma unroll
+                for (int q = 0; q < NPR; ++q) issue_piece(q, j);
+            }
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPR) : "memory");
+            __builtin_amdgcn_s_barrier();
+            load_frags(0, fb0, fa0);
+            int st = 0;
+            while (true) {
+                advance();                                        // step st + 3
+                do_step(st, fb0, fa0, fb1, fa1);
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPR) : "memory");      // my pieces of step st + 2 have landed ...
+                __builtin_amdgcn_s_barrier();                                    // ... everybody's have; stage st is free
+                if (++st == nsteps) break;
+                advance();
+                do_step(st, fb1, fa1, fb0, fa0);
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPR) : "memory");
+                __builtin_amdgcn_s_barrier();
+                if (++st == nsteps) break;
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // trailing zero fills must not land in the epilogue's LDS
+        conv_wide_epilogue<DT, BN, MODE, FY, RELU>(p, acc, smem, b, th * p.tiles_w + tw, h0, w0, n0);
+        return;
     }
     int buf = 0;
     uint4 bf0[4], af0[MB], bf1[4], af1[MB];      // K-half 0 / 1 fragments; a staggered wave keeps half 1 across the barrier
@@ -747,6 +910,16 @@ int conv_wide_tile(const ConvParams& p) {
 template <int DT, int BN, int MODE, bool FY = false, bool RELU = false>
 static int launch_mode(const ConvParams& p, hipStream_t stream) {
     const long long grid = (long long)p.B * p.tiles_h * p.tiles_w * p.n_tiles_n;
+#ifdef CW_WITH_RING      // variant builds only (tools/build_variant.sh ring -DCW_WITH_RING): measured 3.5 % SLOWER
+    if constexpr (BN >= 128) {
+        if (config().conv_ring) {      // CUTIE_CONV_RING=1 selects it
+            CUTIE_ENSURE_LDS((conv_wide_kernel<DT, BN, MODE, FY, RELU, true>), Shape<BN>::LDS);
+            hipLaunchKernelGGL((conv_wide_kernel<DT, BN, MODE, FY, RELU, true>), dim3((unsigned)grid), dim3(CW_NT), Shape<BN>::LDS, stream, p);
+            CUTIE_CHECK_LAUNCH();
+            return CUTIE_OK;
+        }
+    }
+#endif
     CUTIE_ENSURE_LDS((conv_wide_kernel<DT, BN, MODE, FY, RELU>), Shape<BN>::LDS);
     hipLaunchKernelGGL((conv_wide_kernel<DT, BN, MODE, FY, RELU>), dim3((unsigned)grid), dim3(CW_NT), Shape<BN>::LDS, stream, p);
     CUTIE_CHECK_LAUNCH();

@@ -15,7 +15,7 @@ static bool env_on(const char* name, bool dflt = true) {
     const char* v = getenv(name);
     return v ? atoi(v) != 0 : dflt;
 }
-static const Config g_config = {env_on("CUTIE_CONV_WIDE"), env_on("CUTIE_FUSE_NORM_BWD"), env_on("CUTIE_CONV_LPT"), env_on("CUTIE_RENDEZVOUS")};
+static const Config g_config = {env_on("CUTIE_CONV_WIDE"), env_on("CUTIE_FUSE_NORM_BWD"), env_on("CUTIE_CONV_LPT"), env_on("CUTIE_RENDEZVOUS"), env_on("CUTIE_CONV_RING", false)};
 const Config& config() { return g_config; }
 
 // hipFuncAttributeMaxDynamicSharedMemorySize is a property of (kernel, device): set when a kernel first needs more
