@@ -456,7 +456,8 @@ constexpr int WG5_XROWS = 96;  // staged patch rows (24 pieces): 64 + 2 * pad <=
 constexpr int WG5_XROWS_WIDE = 128;   // ... or 32 pieces = the whole patch buffer (WIDEPATCH instances)
 // LDS map: x patch 0 at 0, x patch 1 at 32 KB, dz rows at 64 KB and 80 KB (the halves toggle by XOR)
 constexpr int WG5_XSTRIDE = 32768, WG5_D0 = 65536, WG5_DBUF = WG5_PIX * 256;
-constexpr int WG5_LDS = WG5_D0 + 2 * WG5_DBUF;
+// LDS per workgroup: 96 KB; the wide 1x1 instance (256 cin x 256 cout a workgroup) stages two cout tiles of dz per half: 128 KB
+constexpr int wg5_lds(int kw, bool narrow) { return WG5_D0 + 2 * WG5_DBUF * ((kw == 1 && !narrow) ? 2 : 1); }
 
 struct Wgrad5Params {
     const char* x;
@@ -487,9 +488,16 @@ __device__ __forceinline__ void wgrad5_body(const Wgrad5Params& p, const int spl
     constexpr int MBLK = NARROW ? 1 : 2;     // 16-channel cin blocks per wave
     constexpr int ROWB = 256;       // bytes per staged pixel row: 128 channels
     constexpr bool TWO = KW == 1;   // two cin tiles per workgroup in place of taps
+    // ... and, on the wide 1x1 layers, two cout tiles as well: 256 cin x 256 cout a workgroup, 64 MFMAs a wave out of a
+    // staged row (64 KB) where 256 x 128 gave 32 out of 48 KB - a 1x1 weight gradient is a plain GEMM with K = pixels and
+    // lives on operand reuse alone (round 3: 111 -> see DESIGN.md)
+    constexpr bool QUAD = TWO && !NARROW;
+    constexpr int NCT = QUAD ? 2 : 1;        // cout tiles per workgroup
     constexpr int NT_ = TWO ? 2 : KW;        // accumulator sets: taps, or cin tiles
     constexpr int NX = (TWO || WIDEPATCH) ? 4 : 3;   // x pieces per wave and row
-    constexpr int NPC = NX + 2;              // + the two dz pieces
+    constexpr int ND = 2 * NCT;              // dz pieces per wave and row
+    constexpr int NPC = NX + ND;
+    constexpr int DBUF = WG5_DBUF * NCT;     // one half of the dz image
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int pwx = WG5_PIX + 2 * p.pad;                    // patch rows that hold data
 
@@ -504,20 +512,22 @@ __device__ __forceinline__ void wgrad5_body(const Wgrad5Params& p, const int spl
     const int mt = bid % p.mt;
     const int ti = bid / p.mt;                 // tap row
     const int sy = (ti - p.kh / 2) * dil;
-    const int m0 = mt * (TWO ? 256 : 128), n0 = nt * 128;
+    const int m0 = mt * (TWO ? 256 : 128), n0 = nt * (128 * NCT);
 
     const int units_total = p.B * H * p.nwseg;  // a unit = (sample, image row, 64-pixel column segment)
     const int per = (units_total + p.splits - 1) / p.splits;
     const int unit_begin = split * per;
     const int unit_end = min(units_total, unit_begin + per);
 
-    float4_t acc[NT_][MBLK][4];
+    float4_t acc[NT_][NCT][MBLK][4];
 #pragma unroll
     for (int t = 0; t < NT_; ++t)
 #pragma unroll
-        for (int m = 0; m < MBLK; ++m)
+        for (int c = 0; c < NCT; ++c)
 #pragma unroll
-            for (int n = 0; n < 4; ++n) acc[t][m][n] = float4_t{0.f, 0.f, 0.f, 0.f};
+            for (int m = 0; m < MBLK; ++m)
+#pragma unroll
+                for (int n = 0; n < 4; ++n) acc[t][c][m][n] = float4_t{0.f, 0.f, 0.f, 0.f};
 
     const long long xbytes = ((long long)(p.B * H * W - 1) * p.ld_x + p.cin) * ES;
     const long long dbytes = ((long long)(p.B * H * W - 1) * p.ld_dz + p.cout) * ES;
@@ -530,8 +540,8 @@ __device__ __forceinline__ void wgrad5_body(const Wgrad5Params& p, const int spl
     // channel chunk ((s >> 1) ^ tr_func(row)) * 2 + (s & 1): the swizzle the transposed reads
     // below expect, applied on the SOURCE address.  Rows past the patch get zeros.
     const int prow = lane >> 4, pslot = lane & 15;
-    int x_r[NX], x_off[NX], d_r[2], d_off[2];
-    bool x_ok[NX], d_ok[2];
+    int x_r[NX], x_off[NX], d_r[ND], d_off[ND];
+    bool x_ok[NX], d_ok[ND];
 #pragma unroll
     for (int u = 0; u < NX; ++u) {
         // TWO: pieces 0, 1 are the 64 rows of cin tile 0, pieces 2, 3 those of cin tile 1
@@ -541,9 +551,9 @@ __device__ __forceinline__ void wgrad5_body(const Wgrad5Params& p, const int spl
         x_off[u] = ((x_r[u] - pad) * p.ld_x + chn) * ES;
     }
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
-        d_r[u] = (wave + 8 * u) * 4 + prow;
-        const int chn = n0 + ((((pslot >> 1) ^ tr_func(d_r[u])) << 1) | (pslot & 1)) * 8;
+    for (int u = 0; u < ND; ++u) {      // pieces 0, 1: the 64 rows of cout tile 0; 2, 3 (QUAD): those of cout tile 1
+        d_r[u] = (wave + 8 * (u & 1)) * 4 + prow;
+        const int chn = n0 + (u >> 1) * 128 + ((((pslot >> 1) ^ tr_func(d_r[u])) << 1) | (pslot & 1)) * 8;
         d_ok[u] = chn < p.cout;
         d_off[u] = (d_r[u] * p.ld_dz + chn) * ES;
     }
@@ -567,7 +577,7 @@ __device__ __forceinline__ void wgrad5_body(const Wgrad5Params& p, const int spl
         } else {
             const int u = k - NX;
             const bool ok = live && d_ok[u] && ws + d_r[u] < W;
-            glds16(rsrc_d, lds0 + WG5_D0 + bsel * WG5_DBUF + (wave + 8 * u) * 1024,
+            glds16(rsrc_d, lds0 + WG5_D0 + bsel * DBUF + (u >> 1) * WG5_DBUF + (wave + 8 * (u & 1)) * 1024,
                    ok ? (unsigned)(((b * H + h) * W + ws) * p.ld_dz * ES + d_off[u]) : BUF_OOB);
         }
     };
@@ -622,9 +632,12 @@ __device__ __forceinline__ void wgrad5_body(const Wgrad5Params& p, const int spl
                 }
                 continue;
             }
-            short8_t bf[4];
+            short8_t bf[NCT][4];
 #pragma unroll
-            for (int n = 0; n < 4; ++n) bf[n] = tr2((da ^ (n * 32)) + ks * 32 * ROWB, (da ^ (n * 32)) + ks * 32 * ROWB + 4 * ROWB);
+            for (int c = 0; c < NCT; ++c)
+#pragma unroll
+                for (int n = 0; n < 4; ++n)
+                    bf[c][n] = tr2((da ^ (n * 32)) + c * WG5_DBUF + ks * 32 * ROWB, (da ^ (n * 32)) + c * WG5_DBUF + ks * 32 * ROWB + 4 * ROWB);
 #pragma unroll
             for (int t = 0; t < NT_; ++t) {
                 if (ks == 0) {
@@ -641,14 +654,16 @@ __device__ __forceinline__ void wgrad5_body(const Wgrad5Params& p, const int spl
                 for (int m = 0; m < MBLK; ++m)
                     af[m] = tr2((xa[t][0] ^ (m * 32)) + ks * 32 * ROWB, (xa[t][1] ^ (m * 32)) + ks * 32 * ROWB);
 #pragma unroll
-                for (int m = 0; m < MBLK; ++m)
+                for (int c = 0; c < NCT; ++c)
 #pragma unroll
-                    for (int n = 0; n < 4; ++n)
-                        acc[t][m][n] = mma16<DT>(af[m], bf[n], acc[t][m][n]);
+                    for (int m = 0; m < MBLK; ++m)
+#pragma unroll
+                        for (int n = 0; n < 4; ++n)
+                            acc[t][c][m][n] = mma16<DT>(af[m], bf[c][n], acc[t][c][m][n]);
             }
         }
         // switch halves by +- the stride (not XOR: a dead tap's base row may be negative)
-        const int dxa = buf ? -WG5_XSTRIDE : WG5_XSTRIDE, dda = buf ? -WG5_DBUF : WG5_DBUF;
+        const int dxa = buf ? -WG5_XSTRIDE : WG5_XSTRIDE, dda = buf ? -DBUF : DBUF;
         buf ^= 1;
         da += dda;
 #pragma unroll
@@ -661,15 +676,17 @@ __device__ __forceinline__ void wgrad5_body(const Wgrad5Params& p, const int spl
     for (int t = 0; t < NT_; ++t) {
         float* slab = p.slabs + ((long long)split * p.kh * KW + (TWO ? ti : ti * KW + t)) * p.cin * p.cout;
 #pragma unroll
-        for (int m = 0; m < MBLK; ++m)
+        for (int c = 0; c < NCT; ++c)
 #pragma unroll
-            for (int n = 0; n < 4; ++n)
+            for (int m = 0; m < MBLK; ++m)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int ci = m0 + (TWO ? t * 128 : 0) + (wm * MBLK + m) * 16 + lg * 4 + r;
-                    const int co = n0 + (wn * 4 + n) * 16 + li;
-                    if (ci < p.cin && co < p.cout) slab[(long long)ci * p.cout + co] = acc[t][m][n][r];
-                }
+                for (int n = 0; n < 4; ++n)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int ci = m0 + (TWO ? t * 128 : 0) + (wm * MBLK + m) * 16 + lg * 4 + r;
+                        const int co = n0 + c * 128 + (wn * 4 + n) * 16 + li;
+                        if (ci < p.cin && co < p.cout) slab[(long long)ci * p.cout + co] = acc[t][c][m][n][r];
+                    }
     }
 }
 
@@ -766,7 +783,7 @@ __device__ __forceinline__ void wgrad_reduce_body(const float* __restrict__ slab
 }
 
 inline int wgrad5_splits(int B, int H, int W, int cin, int cout, int kh, int kw) {
-    const long long groups = (long long)kh * cutie::cdiv(cin, kw == 1 ? 256 : 128) * cutie::cdiv(cout, 128);
+    const long long groups = (long long)kh * cutie::cdiv(cin, kw == 1 ? 256 : 128) * cutie::cdiv(cout, (kw == 1 && cout > 64) ? 256 : 128);
     long long s = 256 / groups;                 // about one 512-lane workgroup per CU
     const long long units = (long long)B * H * cutie::cdiv(W, WG5_PIX);
     if (s > units) s = units;
@@ -1106,7 +1123,7 @@ bool plan_wgrad5(const void* x, int ld_x, int cin, const void* dz, int ld_dz, in
     q.B = B; q.H = H; q.W = W; q.kh = kh; q.kw = kw; q.dil = dil;
     q.slabs = nullptr; q.splits = 1;
     q.mt = (int)cutie::cdiv(cin, kw == 1 ? 256 : 128);
-    q.ntile = (int)cutie::cdiv(cout, 128);
+    q.ntile = (int)cutie::cdiv(cout, (kw == 1 && cout > 64) ? 256 : 128);      // 1x1, not narrow: two cout tiles a workgroup
     q.nwseg = (int)cutie::cdiv(W, WG5_PIX);
     // halo columns: with one 64-pixel segment per row everything beyond the image is zero
     // padding and a live 32-pixel K block reaches at most |shift| mod 32 columns outside
@@ -1258,8 +1275,9 @@ extern "C" int cutie_conv_wgrad(const void* x, int ld_x, int cin, const void* dz
         wg5_dispatch(dtype, key, [&](auto dt, auto kwc, auto maskc, auto narrowc, auto widec) {
             constexpr auto fn = wgrad5_kernel<decltype(dt)::value, decltype(kwc)::value, decltype(maskc)::value,
                                               decltype(narrowc)::value, decltype(widec)::value>;
-            cutie::ensure_dyn_lds((const void*)fn, WG5_LDS);
-            hipLaunchKernelGGL(fn, grid5, dim3(WG5_NT), WG5_LDS, stream, q);
+            constexpr int lds5 = wg5_lds(decltype(kwc)::value, decltype(narrowc)::value);
+            cutie::ensure_dyn_lds((const void*)fn, lds5);
+            hipLaunchKernelGGL(fn, grid5, dim3(WG5_NT), lds5, stream, q);
         });
         CUTIE_CHECK_LAUNCH();
         hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)g_red), dim3(256), 0, stream, (const float*)workspace,
@@ -1400,8 +1418,9 @@ extern "C" int cutie_conv_wgrad_batched(const cutie_wgrad_desc* descs, int n, in
         wg5_dispatch(dtype, pl.key[first], [&](auto dt, auto kwc, auto maskc, auto narrowc, auto widec) {
             constexpr auto fn = wgrad5_batched_kernel<decltype(dt)::value, decltype(kwc)::value, decltype(maskc)::value,
                                                       decltype(narrowc)::value, decltype(widec)::value>;
-            cutie::ensure_dyn_lds((const void*)fn, WG5_LDS);
-            hipLaunchKernelGGL(fn, grid, dim3(WG5_NT), WG5_LDS, stream, bt);
+            constexpr int lds5 = wg5_lds(decltype(kwc)::value, decltype(narrowc)::value);
+            cutie::ensure_dyn_lds((const void*)fn, lds5);
+            hipLaunchKernelGGL(fn, grid, dim3(WG5_NT), lds5, stream, bt);
         });
         CUTIE_CHECK_LAUNCH();
         first = last;

@@ -792,6 +792,7 @@ __global__ __launch_bounds__(CW_NT) void conv_wide_kernel(ConvParams p) {
 #pragma unroll
                     for (int k = (MB + 1) / 2; k < MB; ++k) af0[k] = *reinterpret_cast<const uint4*>(At + a_rd[0] + k * 2048);
                 }
+                if (!stag && MB > 2 && m + 2 < MB) af0[m + 2] = *reinterpret_cast<const uint4*>(At + a_rd[0] + (m + 2) * 2048);
                 if (m == MB / 2 - 1) {
 #pragma unroll
                     for (int n = 0; n < 4; ++n) bf1[n] = *reinterpret_cast<const uint4*>(Bt + b_rd[1] + n * 2048);
@@ -818,7 +819,10 @@ __global__ __launch_bounds__(CW_NT) void conv_wide_kernel(ConvParams p) {
             }
         };
         auto compute = [&](int bsel, auto prefetch) {
-            load_f0(bsel, (stag && MB > 1) ? (MB + 1) / 2 : MB);
+            // not staggered: only the first two A fragments up front, the others two groups ahead of their MFMAs
+            // (first_half) - the burst of twelve ds_read_b128 a wave right behind the barrier becomes six (round 3:
+            // SQ_LDS_CMD_FIFO_FULL is non-zero in this kernel and zero in wgrad5; +0.2 % of a step, A/B on one box)
+            load_f0(bsel, stag ? (MB > 1 ? (MB + 1) / 2 : MB) : (MB > 2 ? 2 : MB));
             if constexpr (stag) {
                 if (pend) {
                     __builtin_amdgcn_sched_barrier(0);

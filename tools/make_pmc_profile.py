@@ -20,6 +20,8 @@ out = {"source": "tools/gpu_pmc.sh: three rocprofv3 --pmc passes (FETCH_SIZE | W
                      "16-byte-per-lane read stream at half its bytes (MI355X_MICROARCH.md, HBM).  The factor 2 is right for the kernels "
                      "that read 16 B per lane (convs, wgrad, norm passes); for 4-byte-per-lane readers (pack_batched, adam, l2, sumsq) "
                      "read hbm_bytes_raw = (FETCH_SIZE + WRITE_SIZE) * 1024 instead.",
+       "wave_cycle_split": "shares of SQ_WAVE_CYCLES (fourth pass): SQ_WAIT_ANY (parked at s_waitcnt / s_barrier), SQ_WAIT_INST_ANY "
+                           "(has an instruction, cannot issue it: pipe or operand not ready), SQ_ACTIVE_INST_ANY (issuing)",
        "mfma_util": "SQ_VALU_MFMA_BUSY_CYCLES / (4 * SQ_BUSY_CU_CYCLES)", "lds_conflict_share": "SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE",
        "source_sha": kernel_source_sha(), "kernels": {}}
 for k, v in d.items():
@@ -34,6 +36,19 @@ for k, v in d.items():
         e["mfma_gflop_issued_per_launch"] = round(mops * 512 / 1e9, 2)
         if v["SQ_LDS_IDX_ACTIVE"]["avg"] > 0:
             e["lds_conflict_share"] = round(v["SQ_LDS_BANK_CONFLICT"]["avg"] / v["SQ_LDS_IDX_ACTIVE"]["avg"], 4)
+    if "SQ_WAVE_CYCLES" in v and "SQ_WAIT_ANY" in v and v["SQ_WAVE_CYCLES"]["avg"] > 0:
+        wc = v["SQ_WAVE_CYCLES"]["avg"]
+        e["wave_cycle_split"] = {"parked_at_wait_or_barrier": round(v["SQ_WAIT_ANY"]["avg"] / wc, 4),
+                                 "issue_stalled": round(v["SQ_WAIT_INST_ANY"]["avg"] / wc, 4),
+                                 "issue_stalled_on_lds": round(v["SQ_WAIT_INST_LDS"]["avg"] / wc, 4),
+                                 "issuing": round(v["SQ_ACTIVE_INST_ANY"]["avg"] / wc, 4),
+                                 "issuing_valu_incl_mfma": round(v["SQ_ACTIVE_INST_VALU"]["avg"] / wc, 4),
+                                 "issuing_lds": round(v["SQ_ACTIVE_INST_LDS"]["avg"] / wc, 4),
+                                 "issuing_vmem": round(v["SQ_ACTIVE_INST_VMEM"]["avg"] / wc, 4)}
+    for c in ("SQ_LDS_CMD_FIFO_FULL", "SQ_LDS_DATA_FIFO_FULL", "SQ_LDS_ADDR_CONFLICT", "SQ_INST_CYCLES_VMEM_RD",
+              "SQ_VALU_MFMA_COEXEC_CYCLES", "SQ_INSTS_LDS", "SQ_INSTS_MFMA", "SQ_BUSY_CYCLES"):
+        if c in v:
+            e.setdefault("raw", {})[c] = round(v[c]["avg"], 1)
     if k.startswith("at::") or k.startswith("__amd"):
         continue
     out["kernels"][k] = e
