@@ -53,7 +53,7 @@ class ConvTimer(object):
 
     def __init__(self, ops):
         self.ops, self.orig, self.orig_bwd, self.orig_in_fwd = ops, ops.conv_fwd, ops.conv_dgrad_in_bwd, ops.conv_in_fwd
-        self.events, self.flops, self.kinds, self.enabled = [], [], [], False
+        self.events, self.flops, self.kinds, self.labels, self.enabled = [], [], [], [], False
         ops.conv_fwd = self
         ops.conv_dgrad_in_bwd = self.dgrad_in_bwd
         ops.conv_in_fwd = self.in_fwd
@@ -68,6 +68,7 @@ class ConvTimer(object):
         self.events.append((e0, e1))
         self.flops.append(conv_launch_flops(segs, y.shape[0], y.shape[1], y.shape[2], n_out))
         self.kinds.append("forward + instance norm" if r else "forward, then in_apply")
+        self.labels.append(self._label(segs, n_out))
         return r
 
     def dgrad_in_bwd(self, segs, dy, n_out, *a, **kw):
@@ -80,6 +81,7 @@ class ConvTimer(object):
         self.events.append((e0, e1))
         self.flops.append(conv_launch_flops(segs, dy.shape[0], dy.shape[1], dy.shape[2], n_out))
         self.kinds.append("data gradient + norm gradient")
+        self.labels.append(self._label(segs, n_out))
         return r
 
     # Timing events serialise the queue (each one is a barrier packet): bracketing all 28 conv
@@ -97,7 +99,27 @@ class ConvTimer(object):
         self.events.append((e0, e1))
         self.flops.append(conv_launch_flops(segs, out.shape[0], out.shape[1], out.shape[2], n_out))
         self.kinds.append("conv alone")
+        self.labels.append(self._label(segs, n_out))
         return r
+
+    @staticmethod
+    def _label(segs, n_out):
+        return "+".join("%s%dx%d d%d %d" % ("T" if s.get("flip") else "", s["kh"], s["kw"], s["dil"], s["cin"]) for s in segs) + " -> %d" % n_out
+
+    def launch_table(self, peak_tflops):
+        """--launch-table: every conv launch of a step by its position in the step (mean over the instrumented steps)"""
+        if not self.events:
+            return []
+        first = self.labels[0]
+        per = next((i for i in range(1, len(self.labels)) if self.labels[i] == first and self.kinds[i] == self.kinds[0]
+                    and len(self.labels) % i == 0 and self.labels[:i] == self.labels[i:2 * i]), len(self.labels))
+        rows = []
+        for j in range(per):
+            ms = [a.elapsed_time(b) for (a, b) in self.events[j::per]]
+            m = sum(ms) / len(ms)
+            rows.append("%2d %-30s %-34s %7.1f us  %.3f" % (j, self.kinds[j], self.labels[j], 1e3 * m,
+                                                         self.flops[j] / (m * 1e-3) / 1e12 / peak_tflops))
+        return rows
 
     def by_kind(self, peak_tflops):
         """the same quotient per kind of bracket: only 'conv alone' is a conv kernel by itself (round 1's figure was all of
@@ -276,6 +298,7 @@ def main():
     ap.add_argument("--cols", type=int, default=64)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--launch-table", action="store_true", help="stderr: every conv launch of a step with its event time")
     ap.add_argument("--no-alt", "--no-f16", dest="no_alt", action="store_true",
                     help="skip the second pass on the other 16-bit element type (bf16 when the headline is f16)")
     args = ap.parse_args()
@@ -382,6 +405,8 @@ def main():
                                "share_of_step": round(ms / max(1, -(-args.steps // ConvTimer.EVERY)) / (1e3 * dt / args.steps), 4)}
             # the HBM-bound kernels north_star names (gather, loss): event time inside real steps, bytes from the PMC profile
             out["roofline_hbm"], _ = calls.report(B * H * W, E, C)
+            if args.launch_table:
+                print("\n".join(timer.launch_table(peak)), file=sys.stderr, flush=True)
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(C, V, E, H, W, packed)
     if args.dtype in ("f16", "bf16") and not args.no_alt:

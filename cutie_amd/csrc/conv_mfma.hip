@@ -953,7 +953,16 @@ static int conv_fwd_impl(const cutie_conv_seg* segs, int n_segs, int B, int H, i
     CUTIE_CHECK_ARG((long long)B * p.tiles_h * p.tiles_w * p.n_tiles_n < (1ll << 31), "conv_fwd: grid too large");
     // wide layers: 256-pixel x 256-channel tiles fed by LDS-DMA (conv_wide.hip)
     const bool wide_on = cutie::config().conv_wide;
-    const int bn = (wide_on && dtype != CUTIE_F32 && out_dtype == dtype) ? cutie::conv_wide_tile(p) : 0;
+    int bn = (wide_on && dtype != CUTIE_F32 && out_dtype == dtype) ? cutie::conv_wide_tile(p) : 0;
+    // 128-channel tiles on 4-wave workgroups, two a CU (conv_duo_kernel): +10 % on the 128-channel layers, -13 % on the
+    // 256-channel ones, so by default only where the tile is 128 channels anyway
+    // (measured per launch, tools/gpu_launch_table.sh: 256 -> 128 3x5 140 -> 128 us, 64 -> 64 1x1 31 -> 22 us, but the
+    // decoder's 512 -> 64 3x5 156 -> 194 us: a 64-channel tile moves 80 B of A tile per clock either way and the 8-wave
+    // kernel's 64-channel steps suit that better - so 64-channel tiles only where the K loop is short)
+    long long ksteps = 0;
+    for (int s = 0; s < n_segs; ++s) ksteps += (long long)segs[s].kh * segs[s].kw * (segs[s].cin / 64);
+    if ((bn == 128 || (bn == 64 && ksteps <= 16)) && cutie::config().conv_duo >= 1) bn = -bn;
+    else if (bn == 256 && cutie::config().conv_duo >= 2) bn = -128;
     if (bn) {
         ConvParams q = p;
         int th, tcb;
@@ -961,7 +970,7 @@ static int conv_fwd_impl(const cutie_conv_seg* segs, int n_segs, int B, int H, i
         q.TH = th; q.TWB = tcb;
         q.tiles_h = (int)cutie::cdiv(H, th);
         q.tiles_w = (int)cutie::cdiv(W, tcb * 16);
-        q.n_tiles_n = (int)cutie::cdiv(n_out, bn);
+        q.n_tiles_n = (int)cutie::cdiv(n_out, bn < 0 ? -bn : bn);
         if ((long long)B * q.tiles_h * q.tiles_w * q.n_tiles_n < (1ll << 31)) {
             const bool fuse_on = cutie::config().fuse_norm_bwd;
             const bool fuse = nb && fuse_on && !bias && !relu && !stats && nb->a_dtype == dtype && (nb->ld_a * 2) % 16 == 0 && cutie::aligned16(nb->a) &&

@@ -29,9 +29,10 @@ using namespace cutie::convk;
 
 constexpr int CW_NT = 512;
 constexpr int CW_A0 = 0, CW_B0 = 65536, CW_ABUF = 32768;    // LDS map: A0 A1 (32 KB each), B0 B1 (BN * 128 B each)
-template <int BN> struct Shape {
+template <int BN, int NW = 8> struct Shape {
+    static constexpr int NT = NW * 64;          // lanes of the workgroup: 8 waves, or 4 in the two-workgroups-a-CU form (conv_duo_kernel)
     static constexpr int WN = BN / 64;          // waves across the channel tile (each owns 64 channels)
-    static constexpr int WM = 8 / WN;           // waves across the 256 pixels
+    static constexpr int WM = NW / WN;          // waves across the 256 pixels
     static constexpr int MB = 16 / WM;          // 16-pixel blocks per wave: 8 / 4 / 2
     static constexpr int NB = BN / 64;          // 1-KB pieces of the B tile each wave stages per step
     static constexpr int NP = 4 + NB;           // pieces per wave and step (A: always 4)
@@ -158,10 +159,10 @@ __device__ __forceinline__ float row16_sum(float v) {
 // allocates registers for itself (the backward modes hold 64 registers of forward activation across the staging).
 // FY (backward modes): bw_a is the layer's normalised output y (CUTIE_ACT_FROM_Y) - xhat = y, ReLU pattern out of y's bits;
 // RELU (mode 2): the layer has a ReLU.  Compile-time, so that the per-element code holds one formula, not a select of two.
-template <int DT, int BN, int MODE, bool FY, bool RELU>
-__device__ __forceinline__ void conv_wide_epilogue(const ConvParams& p, float4_t (&acc)[Shape<BN>::MB][4], char* smem, int b,
+template <int DT, int BN, int MODE, bool FY, bool RELU, int NW = 8>
+__device__ __forceinline__ void conv_wide_epilogue(const ConvParams& p, float4_t (&acc)[Shape<BN, NW>::MB][4], char* smem, int b,
                                                    int tile, int h0, int w0, int n0) {
-    typedef Shape<BN> S;
+    typedef Shape<BN, NW> S;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -170,7 +171,7 @@ __device__ __forceinline__ void conv_wide_epilogue(const ConvParams& p, float4_t
     const int H = p.H, W = p.W, TCB = p.TWB, n_out = p.n_out;
     typedef typename elem<DT>::type TO;
     constexpr int PPR = BN / 8;          // 16-byte pieces per pixel row
-    constexpr int RG = CW_NT / PPR;      // pixel rows side by side in the store pass: 16 / 32 / 64
+    constexpr int RG = S::NT / PPR;      // pixel rows side by side in the store pass: 16 / 32 / 64
     constexpr int IT = 256 / RG;         // store iterations per lane: 16 / 8 / 4
     const int pc = tid % PPR, rg = tid / PPR;
     constexpr bool bw = MODE == 1 || MODE == 2;
@@ -894,6 +895,200 @@ __global__ __launch_bounds__(CW_NT) void conv_wide_kernel(ConvParams p) {
 }
 
 
+// ---- Two workgroups a CU (round 3, the review's "overlap epilogues with main loops", form (i)): 256 lanes = 4 waves as
+// 2 (pixel halves) x 2 (channel halves), tile = 256 pixels x 128 output channels, a wave owns the same 128 x 64 = 8 x 4
+// accumulators as in conv_wide_kernel.  One K step = (tap, 32 input channels): A tile 256 rows x 64 B, B tile 128 rows x 64 B,
+// 24 KB a stage, THREE stages (72 KB), so that two workgroups share a CU's 160 KB of LDS, its four SIMDs (one wave of each
+// workgroup per SIMD, 256 registers each) and its matrix pipes: one workgroup's barrier, its waits and its epilogue run
+// under the other one's MFMAs.  Stage s+2 is filled while stage s computes; one barrier per step orders both the landing
+// of step s+1 and the reuse of the stage read at step s-1.  The steps run (64-channel chunk, tap, half) - the order in
+// which conv_wide_kernel adds its K halves - and the epilogue is the same function with the same wave / lane partition
+// of the tile, so both kernels produce the same bits.
+constexpr int DUO_NW = 4;
+constexpr int DUO_ABUF = 16384;
+template <int BN> struct Duo {
+    static_assert(BN == 128 || BN == 64, "channel tiles of the 4-wave form");
+    static constexpr int BBUF = BN * 64;
+    static constexpr int STAGE = DUO_ABUF + BBUF;
+    static constexpr int RING = 3 * STAGE;
+    static constexpr int EPI = Shape<BN, DUO_NW>::TAB + 2 * BN * 4;      // the epilogue's staged tile + its tables
+    static constexpr int LDS = RING > EPI ? RING : EPI;
+    static_assert(2 * LDS <= 160 * 1024, "two workgroups a CU");
+};
+
+// BN = 128: waves 2 x 2, a wave owns 128 pixels x 64 channels; BN = 64 (the decoder's 64-channel layers): waves 4 x 1, 64 x 64
+template <int DT, int BN, int MODE, bool FY, bool RELU>
+__global__ __launch_bounds__(DUO_NW * 64, 2) void conv_duo_kernel(ConvParams p) {
+    typedef Shape<BN, DUO_NW> S;
+    typedef Duo<BN> D;
+    constexpr int MB = S::MB;                  // 8 / 4
+    constexpr int NPA = 4, NPB = BN / 64, NP = NPA + NPB;      // 1-KB pieces per wave and step
+    constexpr int DUO_STAGE = D::STAGE;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / S::WN, wn = wave % S::WN;
+    const int li = lane & 15, lg = lane >> 4;
+    const unsigned lds0 = (unsigned)(uintptr_t)((lds_void_t*)smem);
+    const int H = p.H, W = p.W, TCB = p.TWB, n_out = p.n_out;
+    const int TR = p.TH, TC = TCB * 16;
+
+    int bid = blockIdx.x;
+    const int nwg = gridDim.x;
+    int nt, tw, th, b;
+    if (p.perm_n) {
+        const int SX = p.B >> 3;
+        int l = bid >> 3;
+        nt = l % p.n_tiles_n; l /= p.n_tiles_n;
+        b = (bid & 7) * SX + l % SX;
+        const int tile = p.perm[l / SX];
+        th = tile / p.tiles_w;
+        tw = tile - th * p.tiles_w;
+    } else {
+        if ((nwg & 7) == 0 && !p.rv_plain_order) bid = (bid & 7) * (nwg >> 3) + (bid >> 3);
+        nt = bid % p.n_tiles_n; bid /= p.n_tiles_n;
+        tw = bid % p.tiles_w; bid /= p.tiles_w;
+        th = bid % p.tiles_h;
+        b = bid / p.tiles_h;
+    }
+    const int h0 = th * TR, w0 = tw * TC, n0 = nt * BN;
+
+    float4_t acc[MB][4];
+#pragma unroll
+    for (int m = 0; m < MB; ++m)
+#pragma unroll
+        for (int n = 0; n < 4; ++n) acc[m][n] = float4_t{0.f, 0.f, 0.f, 0.f};
+
+    // staging plan: a 1-KB piece is 16 rows x 64 B, lane l = (row l >> 2, 16-byte slot l & 3) fetching chunk slot ^ rswz(row);
+    // wave w moves A pieces 4w..4w+3 and B pieces 2w, 2w+1
+    int ra_h[NPA], ra_w[NPA], ra_c16[NPA], rb_row[NPB], rb_c16[NPB];
+#pragma unroll
+    for (int k = 0; k < NPA; ++k) {
+        const int r = (wave * NPA + k) * 16 + (lane >> 2);      // tile pixel 0..255
+        const int mb = r >> 4;
+        ra_h[k] = h0 + mb / TCB;
+        ra_w[k] = w0 + (mb % TCB) * 16 + (r & 15);
+        ra_c16[k] = ((lane & 3) ^ rswz(r)) * 16;
+    }
+#pragma unroll
+    for (int k = 0; k < NPB; ++k) {
+        const int r = (wave * NPB + k) * 16 + (lane >> 2);      // weight row 0..127 of the channel tile
+        rb_row[k] = n0 + r;
+        rb_c16[k] = ((lane & 3) ^ rswz(r)) * 16;
+    }
+    const int rc16 = (lg ^ rswz(li)) * 16;
+    const int ra_rd = (wm * (MB * 16) + li) * 64 + rc16;              // + m * 1024 per 16-pixel block
+    const int rb_rd = DUO_ABUF + (wn * 64 + li) * 64 + rc16;          // + n * 1024 per 16-channel block
+
+    int stage = 0;       // stage of the step in hand; the ring position survives from segment to segment
+    for (int s = 0; s < p.nseg; ++s) {
+        const Seg g = p.seg[s];
+        const int ncc = g.cin >> 6;
+        unsigned live = 0;
+        for (int i = 0; i < g.kh; ++i) {
+            const int sy = g.sgn * (i - g.kh / 2) * g.dil;
+            if (h0 + sy + TR - 1 < 0 || h0 + sy >= H) continue;
+            for (int j = 0; j < g.kw; ++j) {
+                const int sx = g.sgn * (j - g.kw / 2) * g.dil;
+                if (w0 + sx + TC - 1 < 0 || w0 + sx >= W) continue;
+                live |= 1u << (i * g.kw + j);
+            }
+        }
+        live = __builtin_amdgcn_readfirstlane(live);
+        if (live == 0u) continue;
+        const int nsteps = __builtin_popcount(live) * ncc * 2;
+
+        const long long xbytes = ((long long)(H * W - 1) * g.ld_x + g.cin) * 2;
+        const u32x4s_t rsrc_x = make_rsrc(g.x + (long long)b * H * W * g.ld_x * 2, (unsigned)xbytes);
+        const long long wbytes = ((long long)(g.kh * g.kw - 1) * g.w_tap_stride + (long long)n_out * g.cin) * 2;
+        const u32x4s_t rsrc_w = make_rsrc(g.w, (unsigned)wbytes);
+        int a_base[NPA];
+        unsigned b_base[NPB];
+#pragma unroll
+        for (int k = 0; k < NPA; ++k) a_base[k] = (ra_h[k] * W + ra_w[k]) * g.ld_x * 2 + ra_c16[k];
+#pragma unroll
+        for (int k = 0; k < NPB; ++k) b_base[k] = rb_row[k] < n_out ? (unsigned)(rb_row[k] * g.cin * 2 + rb_c16[k]) : BUF_OOB;
+
+        // the step whose pieces go out next: K half innermost (the two halves of a 128-byte channel chunk), then the taps
+        // (overlapping pixels of one chunk: L2), then the next 64 channels; beyond the last step the pieces are zero fills
+        unsigned irest = live;
+        int icc = 0, ihalf = 1, issued = 0, da = 0, sy = 0, sx = 0;
+        unsigned db = 0;
+        bool ivalid = false;
+        auto advance = [&]() {
+            ivalid = issued < nsteps;
+            ++issued;
+            if (!ivalid) return;
+            if (ihalf == 0) {
+                ihalf = 1;
+                da += 64;
+                db += 64u;
+                return;
+            }
+            ihalf = 0;
+            if (irest == 0u) { irest = live; ++icc; }
+            const int tap = __builtin_ctz(irest);
+            irest &= irest - 1;
+            const int i = tap / g.kw, j = tap - i * g.kw;
+            sy = g.sgn * (i - g.kh / 2) * g.dil;
+            sx = g.sgn * (j - g.kw / 2) * g.dil;
+            da = ((sy * W + sx) * g.ld_x + icc * 64) * 2;
+            db = (unsigned)(((long long)tap * g.w_tap_stride + icc * 64) * 2);
+        };
+        auto issue_piece = [&](int piece, int stg) {
+            const unsigned dst = lds0 + stg * DUO_STAGE;
+            if (piece < NPA) {
+                const int k = piece;
+                const bool ok = ivalid && (unsigned)(ra_h[k] + sy) < (unsigned)H && (unsigned)(ra_w[k] + sx) < (unsigned)W;
+                glds16(rsrc_x, dst + (wave * NPA + k) * 1024, ok ? (unsigned)(a_base[k] + da) : BUF_OOB);
+            } else {
+                const int k = piece - NPA;
+                glds16(rsrc_w, dst + DUO_ABUF + (wave * NPB + k) * 1024, ivalid ? b_base[k] + db : BUF_OOB);
+            }
+        };
+
+        // ---- prologue: the previous segment's trailing zero fills and last fragment reads are over, steps 0 and 1 go out
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        int s1 = stage == 2 ? 0 : stage + 1;
+        advance();
+#pragma unroll
+        for (int q = 0; q < NP; ++q) issue_piece(q, stage);
+        advance();
+#pragma unroll
+        for (int q = 0; q < NP; ++q) issue_piece(q, s1);
+        for (int st = 0; st < nsteps; ++st) {
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NP) : "memory");      // my pieces of this step have landed ...
+            __builtin_amdgcn_s_barrier();                                   // ... everybody's have; the stage of step st - 1 is free
+            const int s2 = s1 == 2 ? 0 : s1 + 1;
+            advance();                                                      // step st + 2 goes into it
+            const char* St = smem + stage * DUO_STAGE;
+            uint4 fb[4], fa[MB];
+#pragma unroll
+            for (int n = 0; n < 4; ++n) fb[n] = *reinterpret_cast<const uint4*>(St + rb_rd + n * 1024);
+            fa[0] = *reinterpret_cast<const uint4*>(St + ra_rd);
+            fa[1] = *reinterpret_cast<const uint4*>(St + ra_rd + 1024);
+#pragma unroll
+            for (int m = 0; m < MB; ++m) {
+                if (m + 2 < MB) fa[m + 2] = *reinterpret_cast<const uint4*>(St + ra_rd + (m + 2) * 1024);
+#pragma unroll
+                for (int q = 0; q < NP; ++q)
+                    if ((q * MB) / NP == m) issue_piece(q, s2);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int n = 0; n < 4; ++n) mma_frag<DT>(fb[n], fa[m], acc[m][n]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            stage = s1;
+            s1 = s2;
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // trailing zero fills must not land in the epilogue's LDS
+    conv_wide_epilogue<DT, BN, MODE, FY, RELU, DUO_NW>(p, acc, smem, b, th * p.tiles_w + tw, h0, w0, n0);
+}
+
+
 }  // namespace
 
 // channel tile for n_out: 256 where it divides, else 128, else 64 (also for n_out < 64 in whole 16-byte pieces);
@@ -914,6 +1109,12 @@ int conv_wide_tile(const ConvParams& p) {
 template <int DT, int BN, int MODE, bool FY = false, bool RELU = false>
 static int launch_mode(const ConvParams& p, hipStream_t stream) {
     const long long grid = (long long)p.B * p.tiles_h * p.tiles_w * p.n_tiles_n;
+    if constexpr (BN < 0) {      // the two-workgroups-a-CU form of the 128- and 64-channel tiles
+        CUTIE_ENSURE_LDS((conv_duo_kernel<DT, -BN, MODE, FY, RELU>), Duo<-BN>::LDS);
+        hipLaunchKernelGGL((conv_duo_kernel<DT, -BN, MODE, FY, RELU>), dim3((unsigned)grid), dim3(DUO_NW * 64), Duo<-BN>::LDS, stream, p);
+        CUTIE_CHECK_LAUNCH();
+        return CUTIE_OK;
+    } else {
 #ifdef CW_WITH_RING      // variant builds only (tools/build_variant.sh ring -DCW_WITH_RING): measured 3.5 % SLOWER
     if constexpr (BN >= 128) {
         if (config().conv_ring) {      // CUTIE_CONV_RING=1 selects it
@@ -928,6 +1129,7 @@ static int launch_mode(const ConvParams& p, hipStream_t stream) {
     hipLaunchKernelGGL((conv_wide_kernel<DT, BN, MODE, FY, RELU>), dim3((unsigned)grid), dim3(CW_NT), Shape<BN>::LDS, stream, p);
     CUTIE_CHECK_LAUNCH();
     return CUTIE_OK;
+    }
 }
 
 template <int DT, int BN>
@@ -990,14 +1192,16 @@ bool conv_wide_rendezvous_ok(const ConvParams& p, int bn, int* plain_order) {
     if (!tile_weights(p, weight, wmin, wmax)) return false;
     const int nt = p.tiles_h * p.tiles_w;
     const int per_sample = nt * p.n_tiles_n;
-    // a sample's workgroups must all be resident at once, one per CU, with room for a second sample beside it
-    if (per_sample > 128 || 2 * per_sample > device_cus()) return false;
+    // a sample's workgroups must all be resident at once, one per CU (two in the 4-wave form, bn < 0), with room for a
+    // second sample beside it
+    const int per_cu = bn < 0 ? 2 : 1;
+    if (per_sample > 128 || 2 * per_sample > per_cu * device_cus()) return false;
     double wavg = 0.0;
     for (int t = 0; t < nt; ++t) wavg += weight[t];
     wavg /= nt;
-    const int cus = device_cus() > 0 ? device_cus() : 256;
+    const int cus = per_cu * (device_cus() > 0 ? device_cus() : 256);
     const double rounds = (double)((long long)p.B * per_sample + cus - 1) / (double)cus;
-    const double step_us = 1.9 * bn / 256.0;
+    const double step_us = 1.9 * (bn < 0 ? -2 * bn : bn) / 256.0;      // (4-wave form: two tiles share a CU's matrix pipes)
     // every channel lane sweeps the granules of all nt tiles, sixteen tiles in flight at a time (~2 us a batch): the first
     // batch is part of the protocol's measured cost below, the others are not (CUTIE2-dilate 256x128, 128 tiles a sample:
     // 363 docs/s with the tiles meeting against 381 without, tools/cutie2_bench.py)
@@ -1019,7 +1223,7 @@ bool conv_wide_fw_rendezvous_ok(const ConvParams& p, int bn, int* plain_order) {
     if (!tile_weights(p, weight, wmin, wmax)) return false;
     const int nt = p.tiles_h * p.tiles_w;
     const int per_sample = nt * p.n_tiles_n;
-    if (per_sample > 128 || nt > 32 || 2 * per_sample > device_cus()) return false;      // (nt: more than two batches of granules to sweep cost more than the pass saves)
+    if (per_sample > 128 || nt > 32 || 2 * per_sample > (bn < 0 ? 2 : 1) * device_cus()) return false;      // (nt: more than two batches of granules to sweep cost more than the pass saves)
     double wavg = 0.0;
     for (int t = 0; t < nt; ++t) wavg += weight[t];
     wavg /= nt;
@@ -1061,6 +1265,8 @@ int launch_conv_wide(const ConvParams& p0, int dtype, int bn, hipStream_t stream
     plan_tile_order(p);
     const bool bf = dtype == CUTIE_BF16;
     switch (bn) {
+        case -128: return bf ? launch_one<CUTIE_BF16, -128>(p, stream) : launch_one<CUTIE_F16, -128>(p, stream);
+        case -64: return bf ? launch_one<CUTIE_BF16, -64>(p, stream) : launch_one<CUTIE_F16, -64>(p, stream);
         case 256: return bf ? launch_one<CUTIE_BF16, 256>(p, stream) : launch_one<CUTIE_F16, 256>(p, stream);
         case 128: return bf ? launch_one<CUTIE_BF16, 128>(p, stream) : launch_one<CUTIE_F16, 128>(p, stream);
         case 64: return bf ? launch_one<CUTIE_BF16, 64>(p, stream) : launch_one<CUTIE_F16, 64>(p, stream);
