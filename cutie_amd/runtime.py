@@ -94,7 +94,13 @@ class Engine(object):
         self.n_total = off
         self.conv_w_names = [s.name for s in conv_w]
         z = lambda: torch.zeros(self.n_total, dtype=torch.float32, device=self.dev)
-        self.params_flat, self.grads_flat = z(), z()
+        self.params_flat = z()
+        # the gradient buffer carries 64 spare floats behind it: slot 0 holds this replica's share of the clip norm that is
+        # not in the buffer itself (the embedding's per-cell rows, embedding_rows_sumsq), so that the LAST all-reduce slice
+        # of the data-parallel step sums it over the ranks with the gradients - no collective of its own
+        self._grads_store = torch.zeros(self.n_total + 64, dtype=torch.float32, device=self.dev)
+        self.grads_flat = self._grads_store[:self.n_total]
+        self.grads_extra = self._grads_store[self.n_total:self.n_total + 1]
         self.params = OrderedDict((s.name, self._view(self.params_flat, s.name)) for s in specs)
         self.grads = OrderedDict((s.name, self._view(self.grads_flat, s.name)) for s in specs)
         self.spec_by_name = OrderedDict((s.name, s) for s in specs)
@@ -311,6 +317,22 @@ class Engine(object):
         P.reg = torch.zeros(1, dtype=torch.float32, device=dev)
         P.gnorm_sq = torch.zeros(1, dtype=torch.float32, device=dev)
         P.bwd_ready = True
+
+    def wgrad_flush_points(self):
+        """Offsets of the flat gradient buffer at which loss_backward(on_ready=...) announces a finished prefix: the end
+        of each of its batched weight-gradient calls (the first one closes when half of the conv range is pending)."""
+        pts, pend = [], 0
+        for n in reversed(self.net.nodes):
+            if n.op != "conv":
+                continue
+            off, cnt, _ = self.offsets[n.name + "/weights"]
+            pend += cnt
+            if pend >= self.n_conv_w // 2:
+                pts.append(_pad(off + cnt, 64))
+                pend = 0
+        if not pts or pts[-1] != self.n_conv_w:
+            pts.append(self.n_conv_w)
+        return pts
 
     def _grad_segments(self, P, name):
         """(dz view, packed dgrad weights, row offset) for every conv that consumes tensor `name`,
@@ -767,8 +789,7 @@ class Engine(object):
     def embedding_rows_sumsq(self, P):
         """sum over this replica's grid cells of |d(embedding output) row|^2, loss scale taken out: the embedding's
         share of tf.clip_by_global_norm (IndexedSlices values, un-deduplicated).  A 1-float device tensor."""
-        if getattr(P, "emb_sq", None) is None:
-            P.emb_sq = torch.zeros(1, dtype=torch.float32, device=self.dev)
+        P.emb_sq = self.grads_extra      # rides behind the gradient buffer (GradBuckets.finish(tail_extra=1))
         P.emb_sq.zero_()
         if hasattr(P, "d_embed"):
             ops.sumsq(P.d_embed.reshape(-1), P.emb_sq, P.scratch, self.loss_scale)     # still scaled: activation dtype

@@ -20,7 +20,7 @@ from .parallel import GradBuckets, dist_info
 
 class Trainer(object):
     def __init__(self, engine, learning_rate=1e-4, clip_norm=10.0, beta1=0.9, beta2=0.999, epsilon=1e-8,
-                 lr_decay_step=13000, lr_decay_factor=0.1, n_buckets=4, check_inputs=False,
+                 lr_decay_step=13000, lr_decay_factor=0.1, n_buckets=2, check_inputs=False,
                  scale_growth_interval=1000, gc_freeze=True):
         self.eng = engine
         self.lr = float(learning_rate)
@@ -44,7 +44,11 @@ class Trainer(object):
         # of the multi-GPU step on a single GPU; a one-rank all-reduce leaves the gradients as they are)
         import torch.distributed as dist
         forced = os.environ.get("CUTIE_DP_FORCE_BUCKETS") == "1" and dist.is_available() and dist.is_initialized()
-        self.buckets = GradBuckets(engine.grads_flat, engine.n_conv_w, n_buckets) if (self.world > 1 or forced) else None
+        # the conv range goes out in the slices that backward finishes it in (Engine.wgrad_flush_points: two batched
+        # weight-gradient calls); n_buckets only matters for an engine without such points
+        pts = engine.wgrad_flush_points() if hasattr(engine, "wgrad_flush_points") and getattr(engine, "wgrad_batch", False) else None
+        self.buckets = (GradBuckets(engine.grads_flat, engine.n_conv_w, n_buckets, bounds=pts)
+                        if (self.world > 1 or forced) else None)
 
     def step(self, batch, fetch=True):
         """batch: {'grid_table', 'gt_classes'[, 'data_image', 'ps_1d_indices']} as next_batch() returns

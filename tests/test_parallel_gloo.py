@@ -69,6 +69,41 @@ def test_grad_buckets_world2(tmp_path, n_front, pieces):
         np.testing.assert_allclose(got[0], want * (step + 1), rtol=0, atol=1e-6)
 
 
+def _worker_extra(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        n, n_front = 900, 640
+        store = torch.zeros(n + 64)
+        flat, extra = store[:n], store[n:n + 1]          # Engine.grads_flat / Engine.grads_extra
+        buckets = GradBuckets(flat, n_front, bounds=[384, n_front])
+        assert buckets.bounds == [384, 640]
+        for step in range(2):
+            flat.copy_(_rank_grads(rank, n) * (step + 1))
+            extra.fill_(float(rank + 1 + step))
+            buckets.ready(384)
+            buckets.ready(n_front)
+            launched = len(buckets.works)
+            buckets.finish(extra=extra)                   # the last slice reaches over `extra`: no collective of its own
+            assert launched == 2
+            np.save(os.path.join(out_dir, "x%d_s%d.npy" % (rank, step)), store.numpy())
+    finally:
+        dist.destroy_process_group()
+
+
+def test_clip_norm_share_rides_in_the_last_slice(tmp_path):
+    world = 2
+    mp.spawn(_worker_extra, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    for step in range(2):
+        got = [np.load(tmp_path / ("x%d_s%d.npy" % (r, step))) for r in range(world)]
+        assert np.array_equal(got[0], got[1])
+        want = sum(_rank_grads(r, 900) for r in range(world)).numpy() * (step + 1)
+        np.testing.assert_allclose(got[0][:900], want, rtol=0, atol=1e-6)
+        assert got[0][900] == sum(r + 1 + step for r in range(world))
+        assert not got[0][901:].any()
+
+
 def test_bucket_bounds_cover_the_front_range_once():
     flat = torch.zeros(5000)
     b = GradBuckets(flat, 4100, n_buckets=4)
