@@ -705,6 +705,14 @@ __global__ __launch_bounds__(CW_NT) void conv_wide_kernel(ConvParams p) {
         return;
     }
     int buf = 0;
+#ifdef CW_DIAG_NOLDSRD      // diagnostic build: fragments are read from LDS in the first two steps only - WRONG results
+#define CW_RD(dst, src) do { if (diag_steps < 2) dst = src; } while (0)
+#else
+#define CW_RD(dst, src) dst = src
+#endif
+#if defined(CW_DIAG_NODMA) || defined(CW_DIAG_NOLDSRD)
+    int diag_steps = 0;      // steps issued so far (diagnostic builds only)
+#endif
     uint4 bf0[4], af0[MB], bf1[4], af1[MB];      // K-half 0 / 1 fragments; a staggered wave keeps half 1 across the barrier
     // the two orders are two separate instances of the whole K loop (one branch per kernel, none per step)
     auto run = [&](auto stag_tag) {
@@ -751,6 +759,9 @@ __global__ __launch_bounds__(CW_NT) void conv_wide_kernel(ConvParams p) {
             db = (unsigned)(((long long)tap * g.w_tap_stride + cc * 64) * 2);
         };
         auto issue_piece = [&](int piece, int bsel) {
+#ifdef CW_DIAG_NODMA      // diagnostic build (tools/build_variant.sh): only the first two steps fetch their tiles - WRONG results
+            if (diag_steps >= 2) return;
+#endif
             if (piece < 4) {
                 const int k = piece;
                 const bool ok = (unsigned)(a_h[k] + sy) < (unsigned)H && (unsigned)(a_w[k] + sx) < (unsigned)W;
@@ -767,10 +778,10 @@ __global__ __launch_bounds__(CW_NT) void conv_wide_kernel(ConvParams p) {
             const char* At = smem + CW_A0 + bsel * CW_ABUF;
             const char* Bt = smem + CW_B0 + bsel * S::BBUF;
 #pragma unroll
-            for (int n = 0; n < 4; ++n) bf0[n] = *reinterpret_cast<const uint4*>(Bt + b_rd[0] + n * 2048);
+            for (int n = 0; n < 4; ++n) CW_RD(bf0[n], *reinterpret_cast<const uint4*>(Bt + b_rd[0] + n * 2048));
 #pragma unroll
             for (int m = 0; m < MB; ++m)
-                if (m < m_end) af0[m] = *reinterpret_cast<const uint4*>(At + a_rd[0] + m * 2048);
+                if (m < m_end) CW_RD(af0[m], *reinterpret_cast<const uint4*>(At + a_rd[0] + m * 2048));
         };
         // first K half: between the groups of 4 MFMAs the pieces of the next step's tiles are
         // sent on their way and the second half's fragments are fetched; the scheduling
@@ -791,16 +802,16 @@ __global__ __launch_bounds__(CW_NT) void conv_wide_kernel(ConvParams p) {
                 }
                 if (stag && m == 0 && MB > 1) {
 #pragma unroll
-                    for (int k = (MB + 1) / 2; k < MB; ++k) af0[k] = *reinterpret_cast<const uint4*>(At + a_rd[0] + k * 2048);
+                    for (int k = (MB + 1) / 2; k < MB; ++k) CW_RD(af0[k], *reinterpret_cast<const uint4*>(At + a_rd[0] + k * 2048));
                 }
-                if (!stag && MB > 2 && m + 2 < MB) af0[m + 2] = *reinterpret_cast<const uint4*>(At + a_rd[0] + (m + 2) * 2048);
+                if (!stag && MB > 2 && m + 2 < MB) CW_RD(af0[m + 2], *reinterpret_cast<const uint4*>(At + a_rd[0] + (m + 2) * 2048));
                 if (m == MB / 2 - 1) {
 #pragma unroll
-                    for (int n = 0; n < 4; ++n) bf1[n] = *reinterpret_cast<const uint4*>(Bt + b_rd[1] + n * 2048);
+                    for (int n = 0; n < 4; ++n) CW_RD(bf1[n], *reinterpret_cast<const uint4*>(Bt + b_rd[1] + n * 2048));
                 }
                 if (m >= MB / 2) {
-                    af1[2 * (m - MB / 2)] = *reinterpret_cast<const uint4*>(At + a_rd[1] + (2 * (m - MB / 2)) * 2048);
-                    af1[2 * (m - MB / 2) + 1] = *reinterpret_cast<const uint4*>(At + a_rd[1] + (2 * (m - MB / 2) + 1) * 2048);
+                    CW_RD(af1[2 * (m - MB / 2)], *reinterpret_cast<const uint4*>(At + a_rd[1] + (2 * (m - MB / 2)) * 2048));
+                    CW_RD(af1[2 * (m - MB / 2) + 1], *reinterpret_cast<const uint4*>(At + a_rd[1] + (2 * (m - MB / 2) + 1) * 2048));
                 }
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -870,10 +881,16 @@ __global__ __launch_bounds__(CW_NT) void conv_wide_kernel(ConvParams p) {
                 rest &= rest - 1;
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifdef CW_DIAG_NOBAR      // diagnostic build: the waves of a workgroup drift apart - WRONG results
+            if (!more)
+#endif
             __builtin_amdgcn_s_barrier();
             if (!more) break;
             step_offsets(ntap, nc);
             const int nb = buf ^ 1;
+#if defined(CW_DIAG_NODMA) || defined(CW_DIAG_NOLDSRD)
+            ++diag_steps;
+#endif
             compute(buf, [&](int q) { issue_piece(q, nb); });
             tap = ntap;
             cc = nc;

@@ -14,12 +14,13 @@ cin = int(sys.argv[4]) if len(sys.argv) > 4 else 256
 cout = int(sys.argv[5]) if len(sys.argv) > 5 else 256
 B, H, W, kh, kw = int(os.environ.get("CB_B", 32)), 64, 64, 3, 5
 dev = "cuda:0"
+TDT, CDT = (torch.bfloat16, capi.BF16) if os.environ.get("CB_DTYPE", "f16") == "bf16" else (torch.float16, capi.F16)
 g = torch.Generator().manual_seed(0)
-x = (torch.randn((B, H, W, cin), generator=g)).to(torch.bfloat16).to(dev)
-dz = (torch.randn((B, H, W, cout), generator=g)).to(torch.bfloat16).to(dev)
+x = (torch.randn((B, H, W, cin), generator=g)).to(TDT).to(dev)
+dz = (torch.randn((B, H, W, cout), generator=g)).to(TDT).to(dev)
 w = (torch.randn((kh, kw, cin, cout), generator=g) * 0.05).to(dev)
-wf, wd = ops.pack_weights(w, capi.BF16)
-out = torch.zeros((B, H, W, cout), dtype=torch.bfloat16, device=dev)
+wf, wd = ops.pack_weights(w, CDT)
+out = torch.zeros((B, H, W, cout), dtype=TDT, device=dev)
 bias = torch.zeros(cout, device=dev)
 stats = torch.zeros((B, ops.conv_stats_tiles(H, W), cout, 2), device=dev)
 dw = torch.zeros((kh, kw, cin, cout), device=dev)

@@ -3,7 +3,7 @@ import csv
 import sys
 
 rows = list(csv.DictReader(open(sys.argv[1])))
-steps = int(sys.argv[2]) if len(sys.argv) > 2 else 45
+steps = int(sys.argv[2]) if len(sys.argv) > 2 else 33
 tot = sum(float(r["TotalDurationNs"]) for r in rows)
 print("kernel time per step: %.3f ms" % (tot / steps / 1e6))
 for r in rows[:int(sys.argv[3]) if len(sys.argv) > 3 else 24]:
