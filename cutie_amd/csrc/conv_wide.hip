@@ -75,6 +75,33 @@ template <int DT> __device__ __forceinline__ void unpack8(const uint4& u, float*
     }
 }
 
+// v_fma_mix_f32: an f32 fused multiply-add whose f16 sources are taken straight from the halves of a packed register and
+// widened exactly - the same value as v_cvt_f32_f16 followed by v_fma_f32 / v_add_f32, in one instruction instead of two or
+// three.  The store passes of the backward epilogues are VALU-bound; hipcc finds this form for about a
+// quarter of their elements only.
+#ifndef CW_MIX
+#define CW_MIX 1      // -DCW_MIX=0 (tools/build_variant.sh): the widened form everywhere, for A/B runs
+#endif
+__device__ __forceinline__ float mix_add(unsigned h2, bool hi, float c) {                    // (float)h + c
+    float d;
+    if (hi) asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(d) : "v"(h2), "v"(c));
+    else asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel_hi:[1,0,0]" : "=v"(d) : "v"(h2), "v"(c));
+    return d;
+}
+__device__ __forceinline__ float mix_fma_hh(unsigned a2, unsigned b2, bool hi, float c) {    // fma((float)a, (float)b, c)
+    float d;
+    if (hi) asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,1,0]" : "=v"(d) : "v"(a2), "v"(b2), "v"(c));
+    else asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel_hi:[1,1,0]" : "=v"(d) : "v"(a2), "v"(b2), "v"(c));
+    return d;
+}
+__device__ __forceinline__ float mix_fma_hf(unsigned a2, bool hi, float b, float c) {        // fma((float)a, b, c)
+    float d;
+    if (hi) asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(d) : "v"(a2), "v"(b), "v"(c));
+    else asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=v"(d) : "v"(a2), "v"(b), "v"(c));
+    return d;
+}
+__device__ __forceinline__ unsigned pair_of(const uint4& u, int e) { return e < 2 ? u.x : (e < 4 ? u.y : (e < 6 ? u.z : u.w)); }
+
 // Rendezvous of a sample's tiles on tagged 8-byte granules (MI355X_MICROARCH.md, granule hand-off).  slots:
 // [B][slot_tiles][2][n_out] {value, tag}; a tile publishes its two sums for channel c with the launch's tag, then
 // every channel lane sweeps the sample's T tiles until all granules carry that tag (bounded) and folds them in slot
@@ -159,9 +186,35 @@ __device__ __forceinline__ float row16_sum(float v) {
 // allocates registers for itself (the backward modes hold 64 registers of forward activation across the staging).
 // FY (backward modes): bw_a is the layer's normalised output y (CUTIE_ACT_FROM_Y) - xhat = y, ReLU pattern out of y's bits;
 // RELU (mode 2): the layer has a ReLU.  Compile-time, so that the per-element code holds one formula, not a select of two.
+// The forward moments of the layer a backward launch differentiates, folded in slot order (exactly as norm.hip's fold takes
+// them) by the channel lanes.  Called BEFORE the K loop: sixteen dependent-free loads whose latency then passes under the
+// main loop instead of standing in front of the epilogue (two registers a lane carried across it).
+template <int BN>
+__device__ __forceinline__ void fold_bw_stats(const ConvParams& p, int b, int n0, float& fs, float& fss) {
+    fs = 0.f;
+    fss = 0.f;
+    const int tid = threadIdx.x;
+    if (tid < BN && n0 + tid < p.n_out) {
+        const float* q = p.bw_stats + ((long long)b * p.bw_stats_tiles * p.n_out + n0 + tid) * 2;
+        for (int t0 = 0; t0 < p.bw_stats_tiles; t0 += 16) {      // sixteen slots in flight together, added in slot order
+            float2 v[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u)
+                v[u] = t0 + u < p.bw_stats_tiles ? *reinterpret_cast<const float2*>(q + (long long)(t0 + u) * p.n_out * 2) : make_float2(0.f, 0.f);
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                if (t0 + u < p.bw_stats_tiles) {
+                    fs += v[u].x;
+                    fss += v[u].y;
+                }
+            }
+        }
+    }
+}
+
 template <int DT, int BN, int MODE, bool FY, bool RELU, int NW = 8>
 __device__ __forceinline__ void conv_wide_epilogue(const ConvParams& p, float4_t (&acc)[Shape<BN, NW>::MB][4], char* smem, int b,
-                                                   int tile, int h0, int w0, int n0) {
+                                                   int tile, int h0, int w0, int n0, float fs, float fss) {
     typedef Shape<BN, NW> S;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -197,7 +250,6 @@ __device__ __forceinline__ void conv_wide_epilogue(const ConvParams& p, float4_t
     // under the staging of the accumulators (mode 2 holds the tile's dy in registers as well and has no room for them
     // beside the accumulators: there they are requested right after the staging stores)
     uint4 av[IT];
-    float fs = 0.f, fss = 0.f;
     auto load_av = [&]() {
 #pragma unroll
         for (int k = 0; k < IT; ++k) {
@@ -210,18 +262,7 @@ __device__ __forceinline__ void conv_wide_epilogue(const ConvParams& p, float4_t
                                                         ((long long)(b * H + h) * W + w) * p.bw_ld_a + n0 + pc * 8);
         }
     };
-    if constexpr (bw) {
-        if constexpr (!rv) load_av();
-        if (tid < BN && n0 + tid < n_out) {
-            // the slots in slot order, exactly as norm.hip's fold takes them
-#pragma unroll 4
-            for (int t = 0; t < p.bw_stats_tiles; ++t) {
-                const float2 v = *reinterpret_cast<const float2*>(p.bw_stats + (((long long)b * p.bw_stats_tiles + t) * n_out + n0 + tid) * 2);
-                fs += v.x;
-                fss += v.y;
-            }
-        }
-    }
+    if constexpr (bw && !rv) load_av();      // (fs, fss: the forward moments, folded before the K loop - fold_bw_stats)
     __syncthreads();
     TO* Cs = reinterpret_cast<TO*>(smem);  // [256 pixels][BN channels]
     float2* wsum = reinterpret_cast<float2*>(smem + S::WSUM);   // [WM][BN]
@@ -391,7 +432,14 @@ __device__ __forceinline__ void conv_wide_epilogue(const ConvParams& p, float4_t
 #endif
                 *reinterpret_cast<uint4*>(dst) = gv;
             }
-            if (bw) {
+            if constexpr (bw && from_y && DT == CUTIE_F16 && CW_MIX) {
+                // g1 += dy, g2 = fma(dy, y, g2) on the packed halves: the same bits as the widened form below
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    g1[e] = mix_add(pair_of(gv, e), e & 1, g1[e]);
+                    g2[e] = mix_fma_hh(pair_of(gv, e), pair_of(av[k], e), e & 1, g2[e]);
+                }
+            } else if (bw) {
                 float g[8], x[8];
                 unpack8<DT>(gv, g);
                 unpack8<DT>(av[k], x);
@@ -453,13 +501,23 @@ __device__ __forceinline__ void conv_wide_epilogue(const ConvParams& p, float4_t
             const int h = h0 + mb / TCB, w = w0 + (mb % TCB) * 16 + (ml & 15);
             if (h < H && w < W && col < n_out) {
                 float g[8], x[8];
-                unpack8<DT>(gvk[k], g);
-                unpack8<DT>(av[k], x);
+                constexpr bool mix = from_y && DT == CUTIE_F16 && CW_MIX;
+                if constexpr (!mix) {
+                    unpack8<DT>(gvk[k], g);
+                    unpack8<DT>(av[k], x);
+                }
                 TO o[8];
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {     // the arithmetic of in_bwd_apply_kernel, operation for operation
-                    const float xh = from_y ? x[e] : (x[e] - mean8[e]) * inv8[e];
-                    float d = inv8[e] * __builtin_fmaf(-xh, m2[e], g[e] - m1[e]);
+                    float d;
+                    if constexpr (mix) {
+                        // fma(-y, m2, dy - m1) = fma(y, -m2, dy + (-m1)), both steps straight off the packed halves
+                        const float t = mix_add(pair_of(gvk[k], e), e & 1, -m1[e]);
+                        d = inv8[e] * mix_fma_hf(pair_of(av[k], e), e & 1, -m2[e], t);
+                    } else {
+                        const float xh = from_y ? x[e] : (x[e] - mean8[e]) * inv8[e];
+                        d = inv8[e] * __builtin_fmaf(-xh, m2[e], g[e] - m1[e]);
+                    }
                     if constexpr (RELU) {
                         const bool active = from_y ? (u16_of(av[k], e) != y0b[e]) : (x[e] > 0.f);
                         if (!active) d = 0.f;
@@ -524,6 +582,8 @@ __global__ __launch_bounds__(CW_NT) void conv_wide_kernel(ConvParams p) {
         b = bid / p.tiles_h;
     }
     const int h0 = th * TR, w0 = tw * TC, n0 = nt * BN;
+    float bw_fs = 0.f, bw_fss = 0.f;
+    if constexpr (MODE == 1 || MODE == 2) fold_bw_stats<BN>(p, b, n0, bw_fs, bw_fss);
 
     float4_t acc[MB][4];
 #pragma unroll
@@ -701,7 +761,7 @@ __global__ __launch_bounds__(CW_NT) void conv_wide_kernel(ConvParams p) {
             }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // trailing zero fills must not land in the epilogue's LDS
-        conv_wide_epilogue<DT, BN, MODE, FY, RELU>(p, acc, smem, b, th * p.tiles_w + tw, h0, w0, n0);
+        conv_wide_epilogue<DT, BN, MODE, FY, RELU>(p, acc, smem, b, th * p.tiles_w + tw, h0, w0, n0, bw_fs, bw_fss);
         return;
     }
     int buf = 0;
@@ -908,7 +968,7 @@ __global__ __launch_bounds__(CW_NT) void conv_wide_kernel(ConvParams p) {
     };
     run(std::false_type{});      // (std::true_type: the staggered schedule of round 2, measured 0.4 % slower, never instantiated)
 
-    conv_wide_epilogue<DT, BN, MODE, FY, RELU>(p, acc, smem, b, th * p.tiles_w + tw, h0, w0, n0);
+    conv_wide_epilogue<DT, BN, MODE, FY, RELU>(p, acc, smem, b, th * p.tiles_w + tw, h0, w0, n0, bw_fs, bw_fss);
 }
 
 
@@ -970,6 +1030,8 @@ __global__ __launch_bounds__(DUO_NW * 64, 2) void conv_duo_kernel(ConvParams p) 
         b = bid / p.tiles_h;
     }
     const int h0 = th * TR, w0 = tw * TC, n0 = nt * BN;
+    float bw_fs = 0.f, bw_fss = 0.f;
+    if constexpr (MODE == 1 || MODE == 2) fold_bw_stats<BN>(p, b, n0, bw_fs, bw_fss);
 
     float4_t acc[MB][4];
 #pragma unroll
@@ -1102,7 +1164,7 @@ __global__ __launch_bounds__(DUO_NW * 64, 2) void conv_duo_kernel(ConvParams p) 
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // trailing zero fills must not land in the epilogue's LDS
-    conv_wide_epilogue<DT, BN, MODE, FY, RELU, DUO_NW>(p, acc, smem, b, th * p.tiles_w + tw, h0, w0, n0);
+    conv_wide_epilogue<DT, BN, MODE, FY, RELU, DUO_NW>(p, acc, smem, b, th * p.tiles_w + tw, h0, w0, n0, bw_fs, bw_fss);
 }
 
 
