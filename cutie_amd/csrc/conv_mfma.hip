@@ -958,10 +958,11 @@ static int conv_fwd_impl(const cutie_conv_seg* segs, int n_segs, int B, int H, i
     // 256-channel ones, so by default only where the tile is 128 channels anyway
     // (measured per launch, tools/gpu_launch_table.sh: 256 -> 128 3x5 140 -> 128 us, 64 -> 64 1x1 31 -> 22 us, but the
     // decoder's 512 -> 64 3x5 156 -> 194 us: a 64-channel tile moves 80 B of A tile per clock either way and the 8-wave
-    // kernel's 64-channel steps suit that better - so 64-channel tiles only where the K loop is short)
+    // kernel's 64-channel steps suit that better; CUTIE2's 3x3 image-branch layers lost 0.7 % of CUTIE2-ASPP inference - so
+    // 64-channel tiles only for 1x1 layers of up to 256 input channels)
     long long ksteps = 0;
     for (int s = 0; s < n_segs; ++s) ksteps += (long long)segs[s].kh * segs[s].kw * (segs[s].cin / 64);
-    if ((bn == 128 || (bn == 64 && ksteps <= 16)) && cutie::config().conv_duo >= 1) bn = -bn;
+    if ((bn == 128 || (bn == 64 && ksteps <= 4)) && cutie::config().conv_duo >= 1) bn = -bn;
     else if (bn == 256 && cutie::config().conv_duo >= 2) bn = -128;
     if (bn) {
         ConvParams q = p;
