@@ -170,9 +170,11 @@ int cutie_conv_in_fwd(const cutie_conv_seg* segs /* host */, int n_segs,
  * not own are left alone - zero `red` once when it is allocated); otherwise the conv is followed by
  * cutie_in_bwd_stats over all red_tiles slots.  red_tiles >= cutie_conv_stats_tiles(H, W).
  * CUTIE_FUSE_NORM_BWD=0 in the environment WHEN THE LIBRARY IS LOADED selects the two-pass form (A/B
- * measurements; the library reads its four switches - CUTIE_CONV_WIDE, CUTIE_FUSE_NORM_BWD, CUTIE_CONV_LPT,
- * CUTIE_RENDEZVOUS, each "0" to turn the named path off - once at load, never per call; none of them changes results
- * beyond the rounding differences documented at the entry points). */
+ * measurements; the library reads its five switches - CUTIE_CONV_WIDE, CUTIE_FUSE_NORM_BWD, CUTIE_CONV_LPT,
+ * CUTIE_RENDEZVOUS, each "0" to turn the named path off, and CUTIE_CONV_DUO (0: no 4-wave conv kernel, 1 = default:
+ * for 128-channel tiles and short 64-channel 1x1 launches, 2: for the 256-channel layers too) - once at load, never
+ * per call; none of them changes results beyond the rounding differences documented at the entry points;
+ * CUTIE_CONV_RING is read too but selects nothing outside a -DCW_WITH_RING variant build). */
 int cutie_conv_dgrad_in_stats(const cutie_conv_seg* segs /* host */, int n_segs,
                               int B, int H, int W, int n_out,
                               void* out, int ld_out, int out_dtype,

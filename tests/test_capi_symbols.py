@@ -27,6 +27,15 @@ def test_header_symbols_exported_and_bound():
     assert lib.cutie_version() >= 100
 
 
+def test_integration_table_names_every_symbol():
+    """INTEGRATION.md's table (C entry point -> what it replaces in the reference) covers the whole ABI"""
+    with open(os.path.join(REPO, "INTEGRATION.md")) as f:
+        text = f.read()
+    named = set(re.findall(r"`(cutie_[a-z0-9_]+)`", text))
+    missing = [s for s in declared_symbols() if s not in named]
+    assert not missing, "INTEGRATION.md does not mention %s" % missing
+
+
 def test_argument_errors_are_reported_not_thrown():
     lib = capi.lib()
     rc = lib.cutie_grid_build(None, None, None, None, None, 1, 0, 4, 4, 7, None, None, None, None, None, None,
