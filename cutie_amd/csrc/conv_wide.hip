@@ -770,7 +770,7 @@ __global__ __launch_bounds__(CW_NT) void conv_wide_kernel(ConvParams p) {
 #else
 #define CW_RD(dst, src) dst = src
 #endif
-#if defined(CW_DIAG_NODMA) || defined(CW_DIAG_NOLDSRD)
+#if defined(CW_DIAG_NODMA) || defined(CW_DIAG_NOLDSRD) || defined(CW_DIAG_OOBDMA)
     int diag_steps = 0;      // steps issued so far (diagnostic builds only)
 #endif
     uint4 bf0[4], af0[MB], bf1[4], af1[MB];      // K-half 0 / 1 fragments; a staggered wave keeps half 1 across the barrier
@@ -822,14 +822,19 @@ __global__ __launch_bounds__(CW_NT) void conv_wide_kernel(ConvParams p) {
 #ifdef CW_DIAG_NODMA      // diagnostic build (tools/build_variant.sh): only the first two steps fetch their tiles - WRONG results
             if (diag_steps >= 2) return;
 #endif
+#ifdef CW_DIAG_OOBDMA      // diagnostic build: after the first two steps every piece is issued out of range - the LDS-DMA's issue and
+            const bool oob = diag_steps >= 2;      // its LDS write (zeros) without the memory side; use with CW_DIAG_NOLDSRD - WRONG results
+#else
+            constexpr bool oob = false;
+#endif
             if (piece < 4) {
                 const int k = piece;
-                const bool ok = (unsigned)(a_h[k] + sy) < (unsigned)H && (unsigned)(a_w[k] + sx) < (unsigned)W;
+                const bool ok = !oob && (unsigned)(a_h[k] + sy) < (unsigned)H && (unsigned)(a_w[k] + sx) < (unsigned)W;
                 glds16(rsrc_x, lds0 + CW_A0 + bsel * CW_ABUF + wave * 4096 + k * 1024,
                        ok ? (unsigned)(a_base[k] + da) : BUF_OOB);
             } else {
                 const int k = piece - 4;    // an out-of-range weight row stays out of range after + db
-                glds16(rsrc_w, lds0 + CW_B0 + bsel * S::BBUF + wave * (NB * 1024) + k * 1024, b_base[k] + db);
+                glds16(rsrc_w, lds0 + CW_B0 + bsel * S::BBUF + wave * (NB * 1024) + k * 1024, oob ? BUF_OOB : b_base[k] + db);
             }
         };
         // first-half fragments; a staggered wave takes the upper half of its A fragments later (first_half, m == 0),
@@ -948,7 +953,7 @@ __global__ __launch_bounds__(CW_NT) void conv_wide_kernel(ConvParams p) {
             if (!more) break;
             step_offsets(ntap, nc);
             const int nb = buf ^ 1;
-#if defined(CW_DIAG_NODMA) || defined(CW_DIAG_NOLDSRD)
+#if defined(CW_DIAG_NODMA) || defined(CW_DIAG_NOLDSRD) || defined(CW_DIAG_OOBDMA)
             ++diag_steps;
 #endif
             compute(buf, [&](int q) { issue_piece(q, nb); });
