@@ -18,6 +18,8 @@ struct Config {
     bool conv_lpt;        // CUTIE_CONV_LPT=0: conv_wide tiles in row-major order
     bool rendezvous;      // CUTIE_RENDEZVOUS=0: cutie_conv_dgrad_in_bwd always as data gradient + cutie_in_bwd_apply
     bool conv_ring;       // CUTIE_CONV_RING=1 in a -DCW_WITH_RING variant build: conv_wide's four-stage ring (measured slower)
+    int conv_patch;       // CUTIE_CONV_PATCH=1 in a -DCW_WITH_PATCH variant build: conv_patch_kernel (A operand staged as a patch once
+                          // per chunk) for multi-tap dilation-1 launches on the 64 / 128 tiles (measured, not shipped)
     int conv_duo;         // CUTIE_CONV_DUO: conv_duo_kernel (4-wave workgroups, two a CU, 128-channel tiles) - 0 never, 1 (default)
                           // where the channel tile is 128 anyway (n_out % 256 != 0), 2 for the 256-channel layers as well (measured slower)
 };

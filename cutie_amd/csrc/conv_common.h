@@ -140,6 +140,7 @@ __device__ __forceinline__ void glds16(u32x4s_t rsrc, unsigned lds_dst, unsigned
 // segment cin a multiple of 64
 int launch_conv_wide(const convk::ConvParams& p, int dtype, int bn, hipStream_t stream);
 int conv_wide_tile(const convk::ConvParams& p);
+bool conv_patch_ok(const convk::ConvParams& p);      // p.TH / p.TWB set: conv_patch_kernel can take the launch (bn code 1000 + tile)
 bool conv_wide_rendezvous_ok(const convk::ConvParams& p, int bn, int* plain_order);
 bool conv_wide_fw_rendezvous_ok(const convk::ConvParams& p, int bn, int* plain_order);
 

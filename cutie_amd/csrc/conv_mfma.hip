@@ -972,6 +972,8 @@ static int conv_fwd_impl(const cutie_conv_seg* segs, int n_segs, int B, int H, i
         q.tiles_h = (int)cutie::cdiv(H, th);
         q.tiles_w = (int)cutie::cdiv(W, tcb * 16);
         q.n_tiles_n = (int)cutie::cdiv(n_out, bn < 0 ? -bn : bn);
+        // multi-tap dilation-1 launches: the A operand as a patch staged once per chunk (conv_patch_kernel)
+        if (bn > 0 && bn <= 128 && cutie::config().conv_patch >= 1 && cutie::conv_patch_ok(q)) bn += 1000;
         if ((long long)B * q.tiles_h * q.tiles_w * q.n_tiles_n < (1ll << 31)) {
             const bool fuse_on = cutie::config().fuse_norm_bwd;
             const bool fuse = nb && fuse_on && !bias && !relu && !stats && nb->a_dtype == dtype && (nb->ld_a * 2) % 16 == 0 && cutie::aligned16(nb->a) &&

@@ -811,8 +811,14 @@ __global__ __launch_bounds__(CW_NT) void conv_wide_kernel(ConvParams p) {
         // loop can drop the pieces between MFMA groups instead of a burst after the barrier.
         int da = 0, sy = 0, sx = 0;
         unsigned db = 0;
+#ifdef CW_DIAG_SKIPA      // diagnostic build: the A tile is fetched for the first tap of a kw row only - an upper bound of what
+        int diag_j = 0;       // sharing one staged patch between the kw taps could save - WRONG results
+#endif
         auto step_offsets = [&](int tap, int cc) {
             const int i = tap / g.kw, j = tap - i * g.kw;
+#ifdef CW_DIAG_SKIPA
+            diag_j = j;
+#endif
             sy = g.sgn * (i - g.kh / 2) * g.dil;
             sx = g.sgn * (j - g.kw / 2) * g.dil;
             da = ((sy * W + sx) * g.ld_x + cc * 64) * 2;
@@ -828,6 +834,9 @@ __global__ __launch_bounds__(CW_NT) void conv_wide_kernel(ConvParams p) {
             constexpr bool oob = false;
 #endif
             if (piece < 4) {
+#ifdef CW_DIAG_SKIPA
+                if (diag_j != 0) return;
+#endif
                 const int k = piece;
                 const bool ok = !oob && (unsigned)(a_h[k] + sy) < (unsigned)H && (unsigned)(a_w[k] + sx) < (unsigned)W;
                 glds16(rsrc_x, lds0 + CW_A0 + bsel * CW_ABUF + wave * 4096 + k * 1024,
@@ -976,6 +985,223 @@ __global__ __launch_bounds__(CW_NT) void conv_wide_kernel(ConvParams p) {
     conv_wide_epilogue<DT, BN, MODE, FY, RELU>(p, acc, smem, b, th * p.tiles_w + tw, h0, w0, n0, bw_fs, bw_fss);
 }
 
+
+#ifdef CW_WITH_PATCH      // variant builds only (tools/build_variant.sh patch -DCW_WITH_PATCH, CUTIE_CONV_PATCH=1): measured, not shipped
+// ---- The A operand as a PATCH (round 3): conv_wide_kernel stages the 256 shifted pixels of every tap anew, although the
+// taps of a 3 x 5 kernel at dilation 1 read the same 18 x 20 pixels fifteen times over; tools/gpu_diag_loop.sh prices the
+// LDS-DMA at 13 % of a dense launch, 60 % of it on the issue / LDS-write side - fewer pieces is the one lever.  Here the
+// patch of a 64-channel chunk (tile + halo, at most 360 pixels x 128 B = 45 KB) is staged ONCE per chunk, two buffers, and
+// only the B tile (weights of one tap) still moves every step.  The patch's LDS image is pixel-major with a PADDED pixel
+// stride of 144 B (nine 16-byte units, the ninth never read): sixteen consecutive pixels at one chunk then sit 36 banks
+// apart - sixteen different 4-bank groups whatever the tap's shift - so there is no swizzle and a tap is a constant added
+// to the read address, while eight neighbouring DMA lanes still fetch one pixel's 128 contiguous bytes (the ninth lane of
+// each group fetches nothing).  A first version with a chunk-major image (no padding, the DMA gathering 64 cache lines an
+// instruction) ran the decoder's 512 -> 64 layer in 214 us against 157.  Same wave layout, same step order (chunk, tap,
+// K half), same epilogue as conv_wide_kernel: the same bits (the kernel, model and full-shape tests pass with it).
+// Measured per launch inside real steps (bench.py --launch-table, one box): chunk-major form, 256 -> 256 3x5 232.7-237 us
+// against 236 (no gain: 45 % fewer pieces, but a gathering piece costs several coalesced ones), whole step -0.75 %; padded
+// form (does not fit the 256-channel tile's B ring beside two patches): 512 -> 64 3x5 200 us against 159 - the 8-wave
+// 64-channel kernel needs 80 KB of LDS and runs two workgroups a CU, this one 118 KB and one -, 256 -> 128 3x5 130 us against
+// 145 on conv_wide's 128 tile and 129 on conv_duo.  Nothing to ship: what the staging costs is not the number of A bytes.
+constexpr int PT_NPX = 360;                     // patch pixels the image is laid out for
+constexpr int PT_STRIDE = 144;                  // bytes a pixel: eight 16-byte chunks + one unit of padding
+constexpr int PT_PIECES = (PT_NPX * PT_STRIDE + 1023) / 1024;      // 51 one-KB pieces
+constexpr int PT_ABUF = PT_PIECES * 1024;       // 52224 B
+constexpr int PT_ROUNDS = (PT_PIECES + 7) / 8;  // pieces per wave and chunk: 7
+template <int BN> struct Patch {
+    static constexpr int BBUF = BN * 128;
+    static constexpr int B0 = 2 * PT_ABUF;
+    static constexpr int RING = B0 + 2 * BBUF;
+    static constexpr int EPI = Shape<BN>::TAB + 2 * BN * 4;
+    static constexpr int LDS = RING > EPI ? RING : EPI;
+    static constexpr bool FITS = LDS <= 160 * 1024;      // the 256-channel tile's B ring leaves no room for two patches
+};
+
+template <int DT, int BN, int MODE, bool FY, bool RELU>
+__global__ __launch_bounds__(CW_NT) void conv_patch_kernel(ConvParams p) {
+    typedef Shape<BN> S;
+    typedef Patch<BN> PT;
+    constexpr int MB = S::MB, NB = S::NB;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / S::WN, wn = wave % S::WN;
+    const int li = lane & 15, lg = lane >> 4;
+    const unsigned lds0 = (unsigned)(uintptr_t)((lds_void_t*)smem);
+    const int H = p.H, W = p.W, TCB = p.TWB, n_out = p.n_out;
+    const int TR = p.TH, TC = TCB * 16;
+
+    int bid = blockIdx.x;
+    const int nwg = gridDim.x;
+    int nt, tw, th, b;
+    if (p.perm_n) {
+        const int SX = p.B >> 3;
+        int l = bid >> 3;
+        nt = l % p.n_tiles_n; l /= p.n_tiles_n;
+        b = (bid & 7) * SX + l % SX;
+        const int tile = p.perm[l / SX];
+        th = tile / p.tiles_w;
+        tw = tile - th * p.tiles_w;
+    } else {
+        if ((nwg & 7) == 0 && !p.rv_plain_order) bid = (bid & 7) * (nwg >> 3) + (bid >> 3);
+        nt = bid % p.n_tiles_n; bid /= p.n_tiles_n;
+        tw = bid % p.tiles_w; bid /= p.tiles_w;
+        th = bid % p.tiles_h;
+        b = bid / p.tiles_h;
+    }
+    const int h0 = th * TR, w0 = tw * TC, n0 = nt * BN;
+    float bw_fs = 0.f, bw_fss = 0.f;
+    if constexpr (MODE == 1 || MODE == 2) fold_bw_stats<BN>(p, b, n0, bw_fs, bw_fss);
+
+    float4_t acc[MB][4];
+#pragma unroll
+    for (int m = 0; m < MB; ++m)
+#pragma unroll
+        for (int n = 0; n < 4; ++n) acc[m][n] = float4_t{0.f, 0.f, 0.f, 0.f};
+
+    // B tile: staged and read exactly as in conv_wide_kernel (row-major, XOR swizzle)
+    int b_row[NB], b_c16[NB];
+#pragma unroll
+    for (int k = 0; k < NB; ++k) {
+        const int r = wave * (NB * 8) + k * 8 + (lane >> 3);
+        b_row[k] = n0 + r;
+        b_c16[k] = ((lane & 7) ^ swz(r)) * 16;
+    }
+    int b_rd[2];
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) b_rd[kk] = (wn * 64 + li) * 128 + (((kk * 4 + lg) ^ ((li >> 1) & 7)) * 16);
+
+    int buf = 0, abuf = 0;
+    uint4 bf0[4], af0[MB], bf1[4], af1[MB];
+    for (int s = 0; s < p.nseg; ++s) {
+        const Seg g = p.seg[s];
+        const int ncc = g.cin >> 6;
+        const int ntaps = g.kh * g.kw;
+        // the patch: tile + halo (dilation 1, checked by the launcher), rows of PW pixels
+        const int PW = TC + g.kw - 1, PH = TR + g.kh - 1;
+        const int npx = PH * PW;
+        const int ph0 = h0 - g.kh / 2, pw0 = w0 - g.kw / 2;
+
+        const long long xbytes = ((long long)(H * W - 1) * g.ld_x + g.cin) * 2;
+        const u32x4s_t rsrc_x = make_rsrc(g.x + (long long)b * H * W * g.ld_x * 2, (unsigned)xbytes);
+        const long long wbytes = ((long long)(ntaps - 1) * g.w_tap_stride + (long long)n_out * g.cin) * 2;
+        const u32x4s_t rsrc_w = make_rsrc(g.w, (unsigned)wbytes);
+        // wave w moves pieces w, w + 8, ...: unit u = piece * 64 + lane is (patch pixel u / 9, chunk u % 9; chunk 8 = padding)
+        unsigned a_off[PT_ROUNDS];
+#pragma unroll
+        for (int r = 0; r < PT_ROUNDS; ++r) {
+            const int piece = wave + 8 * r;
+            const int u = piece * 64 + lane;
+            const int pp = u / 9, c = u - pp * 9;
+            const int py = pp / PW, px = pp - py * PW;
+            const int h = ph0 + py, w = pw0 + px;
+            const bool ok = piece < PT_PIECES && c < 8 && pp < npx && (unsigned)h < (unsigned)H && (unsigned)w < (unsigned)W;
+            a_off[r] = ok ? (unsigned)((h * W + w) * g.ld_x * 2 + c * 16) : BUF_OOB;
+        }
+        unsigned b_base[NB];
+#pragma unroll
+        for (int k = 0; k < NB; ++k) b_base[k] = b_row[k] < n_out ? (unsigned)(b_row[k] * g.cin * 2 + b_c16[k]) : BUF_OOB;
+        // fragment read address of (pixel block m, lane): the block's patch pixel + li at tap offset 0, chunk lg
+        int a_m[MB];
+#pragma unroll
+        for (int m = 0; m < MB; ++m) {
+            const int mb = wm * MB + m;
+            a_m[m] = ((mb / TCB) * PW + (mb % TCB) * 16 + li) * PT_STRIDE + lg * 16;
+        }
+
+        unsigned db = 0;
+        auto issue_b = [&](int k, int bsel) {
+            glds16(rsrc_w, lds0 + PT::B0 + bsel * PT::BBUF + wave * (NB * 1024) + k * 1024, b_base[k] + db);
+        };
+        auto issue_a = [&](int r, int asel, int cc) {
+            if (wave + 8 * r < PT_PIECES)      // uniform per wave
+                glds16(rsrc_x, lds0 + asel * PT_ABUF + (wave + 8 * r) * 1024, a_off[r] + (unsigned)(cc * 128));
+        };
+        // one sub-step = one tap of one chunk: K halves 0 and 1 from the patch at the tap's offset and the tap's B tile
+        auto compute = [&](int bsel, int asel, int tapoff, auto prefetch) {
+            const char* At = smem + asel * PT_ABUF + tapoff * PT_STRIDE;
+            const char* Bt = smem + PT::B0 + bsel * PT::BBUF;
+            constexpr int KK1 = 64;      // K half 1: chunks 4..7
+#pragma unroll
+            for (int n = 0; n < 4; ++n) bf0[n] = *reinterpret_cast<const uint4*>(Bt + b_rd[0] + n * 2048);
+#pragma unroll
+            for (int m = 0; m < MB; ++m)
+                if (m < 2) af0[m] = *reinterpret_cast<const uint4*>(At + a_m[m]);
+#pragma unroll
+            for (int m = 0; m < MB; ++m) {
+                prefetch(m);
+                if (MB > 2 && m + 2 < MB) af0[m + 2] = *reinterpret_cast<const uint4*>(At + a_m[m + 2]);
+                if (m == MB / 2 - 1) {
+#pragma unroll
+                    for (int n = 0; n < 4; ++n) bf1[n] = *reinterpret_cast<const uint4*>(Bt + b_rd[1] + n * 2048);
+                }
+                if (m >= MB / 2) {
+                    af1[2 * (m - MB / 2)] = *reinterpret_cast<const uint4*>(At + a_m[2 * (m - MB / 2)] + KK1);
+                    af1[2 * (m - MB / 2) + 1] = *reinterpret_cast<const uint4*>(At + a_m[2 * (m - MB / 2) + 1] + KK1);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int n = 0; n < 4; ++n) mma_frag<DT>(bf0[n], af0[m], acc[m][n]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int m = 0; m < MB; ++m)
+#pragma unroll
+                for (int n = 0; n < 4; ++n) mma_frag<DT>(bf1[n], af1[m], acc[m][n]);
+        };
+        auto tap_offset = [&](int t) {      // patch pixels between the tile's origin and the tap's shifted origin
+            const int i = t / g.kw, j = t - i * g.kw;
+            return g.sgn > 0 ? i * PW + j : (g.kh - 1 - i) * PW + (g.kw - 1 - j);
+        };
+
+        __builtin_amdgcn_s_barrier();        // the previous segment's last reads of both rings are done
+#pragma unroll
+        for (int r = 0; r < PT_ROUNDS; ++r) issue_a(r, abuf, 0);
+        db = 0;
+#pragma unroll
+        for (int k = 0; k < NB; ++k) issue_b(k, buf);
+        int t = 0, cc = 0;
+        while (true) {
+            int ntp = t + 1, nc = cc;
+            bool more = true;
+            if (ntp == ntaps) {
+                ntp = 0;
+                nc = cc + 1;
+                more = nc < ncc;
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            if (!more) break;
+            db = (unsigned)(((long long)ntp * g.w_tap_stride + nc * 64) * 2);
+            const int nb = buf ^ 1, na = abuf ^ 1;
+            const bool pa = cc + 1 < ncc;      // the next chunk's patch goes out under this chunk's taps, a piece every other tap or so
+            const int tnow = t, ccn = cc + 1;
+            compute(buf, abuf, tap_offset(t), [&](int m) {
+#pragma unroll
+                for (int q = 0; q < NB; ++q)
+                    if ((q * MB) / (2 * NB) == m) issue_b(q, nb);
+                if (m == (MB > 1 ? 1 : 0) && pa) {
+#pragma unroll
+                    for (int r = 0; r < PT_ROUNDS; ++r)
+                        if ((r * ntaps) / PT_ROUNDS == tnow) issue_a(r, na, ccn);
+                }
+            });
+            t = ntp;
+            if (nc != cc) {
+                cc = nc;
+                abuf = na;
+            }
+            buf = nb;
+        }
+        compute(buf, abuf, tap_offset(t), [&](int) {});
+        buf ^= 1;
+        abuf ^= 1;
+    }
+    conv_wide_epilogue<DT, BN, MODE, FY, RELU>(p, acc, smem, b, th * p.tiles_w + tw, h0, w0, n0, bw_fs, bw_fss);
+}
+
+#endif      // CW_WITH_PATCH
 
 // ---- Two workgroups a CU (round 3, the review's "overlap epilogues with main loops", form (i)): 256 lanes = 4 waves as
 // 2 (pixel halves) x 2 (channel halves), tile = 256 pixels x 128 output channels, a wave owns the same 128 x 64 = 8 x 4
@@ -1175,6 +1401,22 @@ __global__ __launch_bounds__(DUO_NW * 64, 2) void conv_duo_kernel(ConvParams p) 
 
 }  // namespace
 
+// conv_patch_kernel takes a launch when every segment is a multi-tap kernel at dilation 1 whose patch (tile + halo) fits the
+// 360-pixel image: 3 x 5 on 16 x 16 or 8 x 32 tiles
+bool conv_patch_ok(const ConvParams& p) {
+#ifndef CW_WITH_PATCH
+    return false;
+#else
+    const int TC = p.TWB * 16;
+    for (int s = 0; s < p.nseg; ++s) {
+        const Seg& g = p.seg[s];
+        if (g.dil != 1 || g.kh * g.kw < 2) return false;
+        if ((p.TH + g.kh - 1) * (TC + g.kw - 1) > PT_NPX) return false;
+    }
+    return true;
+#endif
+}
+
 // channel tile for n_out: 256 where it divides, else 128, else 64 (also for n_out < 64 in whole 16-byte pieces);
 // 0 = not a wide-kernel shape
 int conv_wide_tile(const ConvParams& p) {
@@ -1193,6 +1435,23 @@ int conv_wide_tile(const ConvParams& p) {
 template <int DT, int BN, int MODE, bool FY = false, bool RELU = false>
 static int launch_mode(const ConvParams& p, hipStream_t stream) {
     const long long grid = (long long)p.B * p.tiles_h * p.tiles_w * p.n_tiles_n;
+#ifndef CW_WITH_PATCH
+    if constexpr (BN > 1000) {
+        set_error("conv_patch: not in this build (-DCW_WITH_PATCH)");
+        return CUTIE_E_ARG;
+    } else
+#else
+    if constexpr (BN > 1000 && !Patch<(BN > 1000 ? BN - 1000 : 64)>::FITS) {
+        set_error("conv_patch: no patch form of the %d-channel tile", BN - 1000);
+        return CUTIE_E_ARG;
+    } else if constexpr (BN > 1000) {      // the A operand staged as a patch, once per 64-channel chunk (conv_patch_kernel)
+        constexpr int PBN = BN - 1000;
+        CUTIE_ENSURE_LDS((conv_patch_kernel<DT, PBN, MODE, FY, RELU>), Patch<PBN>::LDS);
+        hipLaunchKernelGGL((conv_patch_kernel<DT, PBN, MODE, FY, RELU>), dim3((unsigned)grid), dim3(CW_NT), Patch<PBN>::LDS, stream, p);
+        CUTIE_CHECK_LAUNCH();
+        return CUTIE_OK;
+    } else
+#endif
     if constexpr (BN < 0) {      // the two-workgroups-a-CU form of the 128- and 64-channel tiles
         CUTIE_ENSURE_LDS((conv_duo_kernel<DT, -BN, MODE, FY, RELU>), Duo<-BN>::LDS);
         hipLaunchKernelGGL((conv_duo_kernel<DT, -BN, MODE, FY, RELU>), dim3((unsigned)grid), dim3(DUO_NW * 64), Duo<-BN>::LDS, stream, p);
@@ -1271,6 +1530,7 @@ static bool tile_weights(const ConvParams& p, int* weight, int& wmin, int& wmax)
 // heaviest-first order is given up) costs less than the pass over dy, a and dz it replaces (6 bytes per element at
 // ~5 TB/s); a K step of the 256 tile takes ~1.9 us of a tile's wall time (tools/dgrad_bench.py: 230 us for two rounds of 60 steps).
 bool conv_wide_rendezvous_ok(const ConvParams& p, int bn, int* plain_order) {
+    if (bn > 1000) bn -= 1000;      // conv_patch_kernel: the same tiles, one workgroup a CU
     int weight[CONV_MAX_PERM];
     int wmin, wmax;
     if (!tile_weights(p, weight, wmin, wmax)) return false;
@@ -1302,6 +1562,7 @@ bool conv_wide_rendezvous_ok(const ConvParams& p, int bn, int* plain_order) {
 // differently (from the f32 activation / from the stored 16-bit one) and a sample's output must not depend on how
 // many other samples share its batch.
 bool conv_wide_fw_rendezvous_ok(const ConvParams& p, int bn, int* plain_order) {
+    if (bn > 1000) bn -= 1000;
     int weight[CONV_MAX_PERM];
     int wmin, wmax;
     if (!tile_weights(p, weight, wmin, wmax)) return false;
@@ -1349,6 +1610,9 @@ int launch_conv_wide(const ConvParams& p0, int dtype, int bn, hipStream_t stream
     plan_tile_order(p);
     const bool bf = dtype == CUTIE_BF16;
     switch (bn) {
+        case 1256: return bf ? launch_one<CUTIE_BF16, 1256>(p, stream) : launch_one<CUTIE_F16, 1256>(p, stream);
+        case 1128: return bf ? launch_one<CUTIE_BF16, 1128>(p, stream) : launch_one<CUTIE_F16, 1128>(p, stream);
+        case 1064: return bf ? launch_one<CUTIE_BF16, 1064>(p, stream) : launch_one<CUTIE_F16, 1064>(p, stream);
         case -128: return bf ? launch_one<CUTIE_BF16, -128>(p, stream) : launch_one<CUTIE_F16, -128>(p, stream);
         case -64: return bf ? launch_one<CUTIE_BF16, -64>(p, stream) : launch_one<CUTIE_F16, -64>(p, stream);
         case 256: return bf ? launch_one<CUTIE_BF16, 256>(p, stream) : launch_one<CUTIE_F16, 256>(p, stream);

@@ -19,7 +19,7 @@ static int env_int(const char* name, int dflt) {
     const char* v = getenv(name);
     return v ? atoi(v) : dflt;
 }
-static const Config g_config = {env_on("CUTIE_CONV_WIDE"), env_on("CUTIE_FUSE_NORM_BWD"), env_on("CUTIE_CONV_LPT"), env_on("CUTIE_RENDEZVOUS"), env_on("CUTIE_CONV_RING", false), env_int("CUTIE_CONV_DUO", 1)};
+static const Config g_config = {env_on("CUTIE_CONV_WIDE"), env_on("CUTIE_FUSE_NORM_BWD"), env_on("CUTIE_CONV_LPT"), env_on("CUTIE_RENDEZVOUS"), env_on("CUTIE_CONV_RING", false), env_int("CUTIE_CONV_PATCH", 0), env_int("CUTIE_CONV_DUO", 1)};
 const Config& config() { return g_config; }
 
 // hipFuncAttributeMaxDynamicSharedMemorySize is a property of (kernel, device): set when a kernel first needs more
