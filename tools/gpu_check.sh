@@ -12,5 +12,5 @@ rc=$?; tail -3 $O/pytest.log
 timeout -k 10 240 python bench.py > $O/bench.json 2> $O/bench.err || { tail -5 $O/bench.err; exit 1; }
 cat $O/bench.json
 cd /tmp && export TMPDIR=/tmp
-timeout -k 10 240 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -- python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-alt > $O/bench_prof.json 2> $O/prof.err || { tail -5 $O/prof.err; exit 1; }
+timeout -k 10 240 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -- python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-alt --no-clock > $O/bench_prof.json 2> $O/prof.err || { tail -5 $O/prof.err; exit 1; }
 cat $O/bench_prof.json
