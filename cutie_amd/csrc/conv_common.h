@@ -46,7 +46,7 @@ struct ConvParams {
     // publishing its slot of bw_red every tile waits until the sample's other tiles have published theirs, folds all
     // slots and stores dz = act'(a) * inv * (dy - mean(dy) - xhat * mean(dy * xhat)) - what cutie_in_bwd_apply computes -
     // instead of dy, plus its share of the bias gradient.  `out` is not written then.
-    unsigned long long* rv_slots;   // [B][bw_red_tiles][2][n_out] {value, tag} granules (zeroed once by the caller)
+    unsigned long long* rv_slots;   // [B][bw_red_tiles][n_out] 16-byte {s1, tag, s2, tag} granule pairs (zeroed once by the caller)
     char* rv_dz;
     int rv_ld_dz;
     float* rv_dbias;         // [B][rv_dbias_tiles][n_out], tile t of a sample stores row t
@@ -59,7 +59,7 @@ struct ConvParams {
     // Forward rendezvous (conv_wide only, with stats, nullable): the sample's tiles meet after publishing their moments
     // and `out` receives the NORMALISED activation y = (a - mean) * rsqrt(var + fw_eps); a itself is not stored.
     // Shares rv_plain_order / rv_err / rv_late with the backward form.
-    unsigned long long* fw_slots;   // [B][stats_tiles][2][n_out] {value, tag} granules (zeroed once by the caller)
+    unsigned long long* fw_slots;   // [B][stats_tiles][n_out] 16-byte {s1, tag, s2, tag} granule pairs (zeroed once by the caller)
     float fw_eps;
     // conv_wide: order in which an XCD takes the pixel tiles of its samples - heaviest (most live taps)
     // first, so that the light corner tiles of a dilated layer fill the end of the launch.  0 = row-major.

@@ -852,7 +852,7 @@ struct NormBwd {      // the reduction of cutie_in_bwd_stats, asked of a data-gr
     int ld_dz, relu;
     float* dbias;
     int dbias_tiles;
-    unsigned* sync;      // word 0: tiles whose wait ran out; from byte 64: [B][red_tiles][2][n_out] 8-byte granules
+    unsigned* sync;      // word 0: tiles whose wait ran out; from byte 64: [B][red_tiles][n_out] 16-byte granule pairs
     int* late;           // nullable: the caller's step-wide counter of the same event
 };
 }  // namespace
@@ -862,7 +862,7 @@ struct NormFwd {      // cutie_conv_in_fwd: the normalised output, asked of a fo
     void* y;
     int ld_y;
     float eps;
-    unsigned* sync;      // word 0: waits that ran out; from byte 64: [B][stats_tiles][2][n_out] 8-byte granules
+    unsigned* sync;      // word 0: waits that ran out; from byte 64: [B][stats_tiles][n_out] 16-byte granule pairs
     int* late;           // nullable: the caller's step-wide counter of the same event
 };
 }  // namespace

@@ -102,44 +102,52 @@ __device__ __forceinline__ float mix_fma_hf(unsigned a2, bool hi, float b, float
 }
 __device__ __forceinline__ unsigned pair_of(const uint4& u, int e) { return e < 2 ? u.x : (e < 4 ? u.y : (e < 6 ? u.z : u.w)); }
 
-// Rendezvous of a sample's tiles on tagged 8-byte granules (MI355X_MICROARCH.md, granule hand-off).  slots:
-// [B][slot_tiles][2][n_out] {value, tag}; a tile publishes its two sums for channel c with the launch's tag, then
-// every channel lane sweeps the sample's T tiles until all granules carry that tag (bounded) and folds them in slot
-// order.  The tag of a launch is the slot's previous tag + 1: every launch rewrites all slots of its area.
+// Rendezvous of a sample's tiles on tagged granules (MI355X_MICROARCH.md, granule hand-off).  slots:
+// [B][slot_tiles][n_out] 16-byte pairs of 8-byte granules {s1, tag, s2, tag}; a tile publishes its two sums for channel c
+// with the launch's tag in ONE 16-byte write-through store, then every channel lane sweeps the sample's T tiles with ONE
+// 16-byte load a tile until both halves of all of them carry that tag (bounded) and folds them in slot order.  Each 8-byte
+// half validates itself, so nothing depends on the 16 bytes arriving as one (round 3: the two sums were two 8-byte
+// stores and two 8-byte loads a tile before - `sc1` accesses of 8 B cost 2.7x their bytes, and the sweep was 15 us of a
+// dense launch).  The tag of a launch is the slot's previous tag + 1: every launch rewrites all slots of its area.
+constexpr int GR_SC1 = 16;                        // cache policy bit of the buffer builtins: sc1 (served by / written through to L2's memory side)
+constexpr int GR_VOLATILE = (int)0x80000000u;     // ... and "volatile": the polling loads are not to be hoisted or merged
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t granule_rsrc(const unsigned long long* slots, int B, int slot_tiles, int n_out) {
+    return __builtin_amdgcn_make_buffer_rsrc((void*)slots, 0, (int)((long long)B * slot_tiles * n_out * 16), 0x00020000);
+}
+__device__ __forceinline__ unsigned granule_off(int b, int slot_tiles, int tile, int n_out, int c) {
+    return (unsigned)((((long long)b * slot_tiles + tile) * n_out + c) * 16);
+}
 __device__ __forceinline__ unsigned granule_tag(const unsigned long long* slots, int b, int slot_tiles, int tile, int n_out, int c) {
-    return (unsigned)(__hip_atomic_load(slots + (((long long)b * slot_tiles + tile) * 2) * n_out + c, __ATOMIC_RELAXED,
+    return (unsigned)(__hip_atomic_load(slots + (((long long)b * slot_tiles + tile) * n_out + c) * 2, __ATOMIC_RELAXED,
                                         __HIP_MEMORY_SCOPE_AGENT) >> 32) + 1u;
 }
-__device__ __forceinline__ void granule_publish(unsigned long long* slots, int b, int slot_tiles, int tile, int n_out, int c,
+__device__ __forceinline__ void granule_publish(unsigned long long* slots, int B, int b, int slot_tiles, int tile, int n_out, int c,
                                                 unsigned tag, float s1, float s2) {
-    // write-through 8-byte stores (global_store_dwordx2 sc1): whoever reads a granule with the tag has its value
-    unsigned long long* g1 = slots + (((long long)b * slot_tiles + tile) * 2) * n_out + c;
-    __hip_atomic_store(g1, ((unsigned long long)tag << 32) | __float_as_uint(s1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store(g1 + n_out, ((unsigned long long)tag << 32) | __float_as_uint(s2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const u32x4_t v = {__float_as_uint(s1), tag, __float_as_uint(s2), tag};
+    __builtin_amdgcn_raw_buffer_store_b128(v, granule_rsrc(slots, B, slot_tiles, n_out), (int)granule_off(b, slot_tiles, tile, n_out, c), 0, GR_SC1);
 }
-__device__ __forceinline__ void granule_sweep(const unsigned long long* slots, int b, int slot_tiles, int T, int n_out, int c,
+__device__ __forceinline__ void granule_sweep(const unsigned long long* slots, int B, int b, int slot_tiles, int T, int n_out, int c,
                                               unsigned tag, int* err, int* err2, float& r1, float& r2) {
     const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();      // 100 MHz
+    const __amdgpu_buffer_rsrc_t rs = granule_rsrc(slots, B, slot_tiles, n_out);
     bool late = false;
     while (true) {
         bool all = true;
         r1 = 0.f;
         r2 = 0.f;
         for (int tb = 0; tb < T; tb += 16) {       // sixteen tiles' granules in flight together
-            unsigned long long v1[16], v2[16];
+            u32x4_t v[16];
 #pragma unroll
             for (int u = 0; u < 16; ++u) {
                 const int t = tb + u < T ? tb + u : T - 1;
-                const unsigned long long* q = slots + ((long long)b * slot_tiles + t) * 2 * n_out + c;
-                v1[u] = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                v2[u] = __hip_atomic_load(q + n_out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                v[u] = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)granule_off(b, slot_tiles, t, n_out, c), 0, GR_SC1 | GR_VOLATILE);
             }
 #pragma unroll
             for (int u = 0; u < 16; ++u) {
                 if (tb + u < T) {
-                    all = all && (unsigned)(v1[u] >> 32) == tag && (unsigned)(v2[u] >> 32) == tag;
-                    r1 += __uint_as_float((unsigned)v1[u]);
-                    r2 += __uint_as_float((unsigned)v2[u]);
+                    all = all && v[u].y == tag && v[u].w == tag;
+                    r1 += __uint_as_float(v[u].x);
+                    r2 += __uint_as_float(v[u].z);
                 }
             }
         }
@@ -360,9 +368,9 @@ __device__ __forceinline__ void conv_wide_epilogue(const ConvParams& p, float4_t
         if (fw) {
             // forward rendezvous: publish, wait for the sample's other tiles, fold all of them in slot order (the
             // arithmetic of norm.hip's fold_slots<1>) - this lane then knows its channel's mean and 1/sigma
-            granule_publish(p.fw_slots, b, p.stats_tiles, tile, n_out, n0 + tid, fw_tag, s1, s2);
+            granule_publish(p.fw_slots, p.B, b, p.stats_tiles, tile, n_out, n0 + tid, fw_tag, s1, s2);
             float r1, r2;
-            granule_sweep(p.fw_slots, b, p.stats_tiles, p.tiles_h * p.tiles_w, n_out, n0 + tid, fw_tag, p.rv_err, p.rv_late, r1, r2);
+            granule_sweep(p.fw_slots, p.B, b, p.stats_tiles, p.tiles_h * p.tiles_w, n_out, n0 + tid, fw_tag, p.rv_err, p.rv_late, r1, r2);
             const float inv_n = 1.f / (float)(H * W);
             norm_mean_inv(r1, r2, inv_n, norm_shift(p.bias, p.relu, n0 + tid), p.fw_eps, tab[tid], tab[BN + tid]);
         }
@@ -466,7 +474,7 @@ __device__ __forceinline__ void conv_wide_epilogue(const ConvParams& p, float4_t
             s2 += v.y;
         }
         if (rv) {
-            granule_publish(p.rv_slots, b, p.bw_red_tiles, tile, n_out, n0 + tid, rv_tag, s1, s2);
+            granule_publish(p.rv_slots, p.B, b, p.bw_red_tiles, tile, n_out, n0 + tid, rv_tag, s1, s2);
         } else {
             *reinterpret_cast<float2*>(p.bw_red + (((long long)b * p.bw_red_tiles + tile) * n_out + n0 + tid) * 2) = make_float2(s1, s2);
         }
@@ -480,7 +488,7 @@ __device__ __forceinline__ void conv_wide_epilogue(const ConvParams& p, float4_t
     if (tid < BN && n0 + tid < n_out) {
         const float inv_n = 1.f / (float)(H * W);
         float r1, r2;
-        granule_sweep(p.rv_slots, b, p.bw_red_tiles, T, n_out, n0 + tid, rv_tag, p.rv_err, p.rv_late, r1, r2);
+        granule_sweep(p.rv_slots, p.B, b, p.bw_red_tiles, T, n_out, n0 + tid, rv_tag, p.rv_err, p.rv_late, r1, r2);
         tab2[tid] = r1 * inv_n;
         tab2[BN + tid] = r2 * inv_n;
     }

@@ -188,7 +188,7 @@ int cutie_conv_dgrad_in_stats(const cutie_conv_seg* segs /* host */, int n_segs,
  * cutie_conv_dgrad_in_stats followed by cutie_in_bwd_apply (K6 below), asked for as one call:
  *   dz = act'(a) * inv * (dy - mean(dy) - xhat * mean(dy * xhat)),  dbias_part[b*dbias_tiles + t][c] = partial sums of dz.
  * Where the wide MFMA kernel applies, the tiles of a sample take about equally long and at most 128 workgroups
- * make up a sample, ONE launch does it: every tile publishes its two sums as tagged 8-byte granules in `sync`,
+ * make up a sample, ONE launch does it: every tile publishes its two sums as tagged 8-byte granules (stored and swept in 16-byte pairs) in `sync`,
  * sweeps the granules of its sample's other tiles until they carry the launch's tag (a bounded wait), folds them
  * and stores dz straight from the tile - dy is never written and the pass over dy, a and dz does not run (the
  * same bits as the two-call form: same operands, same order).  Otherwise the call runs the two-call form through

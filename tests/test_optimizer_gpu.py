@@ -161,7 +161,8 @@ def test_a_late_tile_skips_the_step_on_the_device(where):
     used = [k for k, t in areas.items() if int(t[16:].abs().max()) > 0]      # the areas a one-launch form has written tags into
     assert used, "no layer took the one-launch %s form at this shape" % where
     area = areas[used[0]]
-    # granules of (sample 0, tile 1): [B][T][2][n_out] 8-byte {value, tag}, 64 bytes in; the tag is the high word
+    # granules of (sample 0, tile 1): [B][T][n_out] pairs of 8-byte {value, tag}, 64 bytes in; the tag is the high word of
+    # each half (2 * n_out 8-byte words a tile, all of them bumped)
     n_out = eng.net.layers[used[0]].channels
     g64 = area[16:].view(torch.int64).view(B, -1, 2, n_out)
     g64[0, 1] += (1000 << 32)
