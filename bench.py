@@ -138,39 +138,24 @@ class ConvTimer(object):
         return sum(ms), sum(self.flops), len(ms)
 
 
-def sample_clock(device_index, step, fence, steps=16, period_s=0.002):
-    """Median / min / max of the shader clock (MHz) while `steps` more steps run; None-valued when amdsmi is not there."""
-    import threading
-    samples, stop = [], threading.Event()
-
-    def poll():
-        while not stop.is_set():
-            try:
-                samples.append(int(torch.cuda.clock_rate(device_index)))
-            except Exception:      # no amdsmi on this box: report that, do not fail the bench
-                return
-            time.sleep(period_s)
-
+def sample_clock(ops, dev, step, fence, steps=8):
+    """The shader clock the chip HOLDS inside the dominant kernel, measured in the kernel: workgroup 0 of every wide conv
+    launch of `steps` extra, untimed steps adds its K loop's shader-clock cycles (s_memtime) and 100 MHz ticks
+    (s_memrealtime) to a probe buffer (cutie_conv_clock_probe)."""
+    probe = torch.zeros(3, dtype=torch.int64, device=dev)
+    ops.conv_clock_probe(probe)
     try:
-        torch.cuda.clock_rate(device_index)
-    except Exception as e:
-        return {"mhz_median": None, "note": "torch.cuda.clock_rate unavailable: %s" % type(e).__name__}
-    for _ in range(4):
-        step()
-    th = threading.Thread(target=poll, daemon=True)
-    th.start()
-    for _ in range(steps):
-        step()
-        torch.cuda.synchronize()      # keep the host beside the device so that the samples fall inside the steps
-    stop.set()
-    th.join(timeout=2.0)
-    fence()
-    if not samples:
-        return {"mhz_median": None, "note": "no samples"}
-    samples.sort()
-    return {"mhz_median": samples[len(samples) // 2], "mhz_min": samples[0], "mhz_max": samples[-1], "samples": len(samples),
-            "mhz_nominal": 2400, "note": "amdsmi current gfx clock while %d untimed steps run (per-step sync); the 2516.6 TFLOP/s "
-                                         "peak assumes 2400 MHz" % steps}
+        for _ in range(steps):
+            step()
+        fence()
+    finally:
+        ops.conv_clock_probe(None)
+    cycles, ticks, launches = (int(v) for v in probe.cpu())
+    if ticks <= 0:
+        return {"mhz": None, "note": "no wide conv launch reported"}
+    return {"mhz": round(100.0 * cycles / ticks, 1), "mhz_nominal": 2400, "launches": launches,
+            "note": "shader-clock cycles / 100 MHz ticks over the K loop of workgroup 0 of every conv_wide launch of %d untimed "
+                    "steps behind the timed region; the 2516.6 TFLOP/s peak assumes 2400 MHz" % steps}
 
 
 def kernel_source_sha():
@@ -443,17 +428,18 @@ def main():
             out["roofline_hbm"], _ = calls.report(B * H * W, E, C)
             if args.launch_table:
                 print("\n".join(timer.launch_table(peak)), file=sys.stderr, flush=True)
+        if not args.no_clock:
+            # the peak is the vendor's 2.4 GHz figure - print the shader clock the chip actually HOLDS under
+            # this step - measured inside the conv kernels themselves on extra, untimed steps behind the timed region (amdsmi's
+            # "current clock" read 1147, 1613 and 2250 MHz for the same step on three boxes: a DPM level, not the clock).
+            clk = sample_clock(ops, dev, step, fence)
+            out["config"]["sclk_under_load"] = clk
+            if clk.get("mhz"):
+                # the same whole-step fraction against the MFMA rate at the clock the chip holds (peak x held / 2400 MHz)
+                out["config"]["whole_step_mfma_frac_at_held_clock"] = round(
+                    out["config"]["whole_step_mfma_frac"] * clk["mhz_nominal"] / clk["mhz"], 4)
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(C, V, E, H, W, packed)
-    if rank == 0 and not args.no_clock:
-        # the peak is the vendor's 2.4 GHz figure - print the shader clock the chip actually HOLDS under this
-        # step.  Sampled (amdsmi through torch.cuda.clock_rate) on a few extra, untimed steps behind the timed region.
-        clk = sample_clock(local, step, fence)
-        out["config"]["sclk_under_load"] = clk
-        if clk.get("mhz_median"):
-            # the same whole-step fraction against the MFMA rate at the clock the chip holds (peak x held / 2400 MHz)
-            out["config"]["whole_step_mfma_frac_at_held_clock"] = round(
-                out["config"]["whole_step_mfma_frac"] * clk["mhz_nominal"] / clk["mhz_median"], 4)
     if args.dtype in ("f16", "bf16") and not args.no_alt:
         # the same step on the other 16-bit element type (same tiles, same MFMA rate): bf16 beside the f16
         # headline.  bf16's 8 significant bits put it outside the 2e-2 logit tolerance (tests/test_model_gpu.py),

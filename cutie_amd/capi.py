@@ -71,6 +71,7 @@ SIGNATURES = {
     "cutie_conv_dgrad_in_stats": (_i, [_c.POINTER(ConvSeg), _i, _i, _i, _i, _i, _vp, _i, _i, _vp, _i, _i, _vp, _i, _f, _vp,
                                        _i, _vp, _i, _i, _vp]),
     "cutie_conv_sync_bytes": (_sz, [_i, _i, _i]),
+    "cutie_conv_clock_probe": (_i, [_vp]),
     "cutie_conv_dgrad_in_bwd": (_i, [_c.POINTER(ConvSeg), _i, _i, _i, _i, _i, _vp, _i, _vp, _i, _vp, _i, _f, _vp, _i, _i,
                                      _vp, _vp, _i, _vp, _i, _vp, _sz, _vp, _i, _vp]),
     "cutie_conv_wgrad_workspace_bytes": (_sz, [_i, _i, _i, _i, _i, _i, _i]),

@@ -65,7 +65,11 @@ struct ConvParams {
     // first, so that the light corner tiles of a dilated layer fill the end of the launch.  0 = row-major.
     int perm_n;
     unsigned char perm[CONV_MAX_PERM];
+    // cutie_conv_clock_probe: nullable; workgroup 0 of a conv_wide launch adds {shader-clock cycles, 100 MHz ticks, 1} of its
+    // own lifetime to these three words - the clock the chip holds under the launch is cycles / ticks x 100 MHz
+    unsigned long long* clk_probe;
 };
+unsigned long long* conv_clock_probe();      // the registered probe buffer of the current process (conv_mfma.hip), or nullptr
 
 template <int DT> struct Traits;
 template <> struct Traits<CUTIE_BF16> { static constexpr int ES = 2; static constexpr int BKE = 64; };

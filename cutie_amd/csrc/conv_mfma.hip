@@ -907,6 +907,7 @@ static int conv_fwd_impl(const cutie_conv_seg* segs, int n_segs, int B, int H, i
     ConvParams p;
     p.nseg = n_segs;
     p.bw_a = nullptr; p.bw_ld_a = 0; p.bw_stats = nullptr; p.bw_stats_tiles = 0; p.bw_eps = 0.f; p.bw_bias = nullptr; p.bw_act = 0; p.bw_red = nullptr; p.bw_red_tiles = 0; p.perm_n = 0;
+    p.clk_probe = nullptr;
     p.rv_slots = nullptr; p.rv_dz = nullptr; p.rv_ld_dz = 0; p.rv_dbias = nullptr; p.rv_dbias_tiles = 0; p.rv_relu = 0; p.rv_plain_order = 0; p.rv_err = nullptr; p.rv_late = nullptr; p.fw_slots = nullptr; p.fw_eps = 0.f;
     int twb, th_g;
     generic_tiling(W, th_g, twb);
@@ -1078,6 +1079,15 @@ extern "C" int cutie_conv_dgrad_in_stats(const cutie_conv_seg* segs, int n_segs,
     const NormBwd nb = {a, ld_a, a_dtype, stats, stats_tiles, eps, red, red_tiles, shift_bias, shift_act,
                         nullptr, 0, 0, nullptr, 0, nullptr, nullptr};
     return conv_fwd_impl(segs, n_segs, B, H, W, n_out, out, ld_out, out_dtype, nullptr, 0, nullptr, 0, dtype, &nb, stream_);
+}
+
+// measurement hook: the probe buffer the conv_wide launches of this process report into (nullptr: none)
+static unsigned long long* g_clock_probe = nullptr;
+namespace cutie { namespace convk { unsigned long long* conv_clock_probe() { return g_clock_probe; } } }
+extern "C" int cutie_conv_clock_probe(void* probe) {
+    CUTIE_CHECK_ARG((reinterpret_cast<uintptr_t>(probe) & 7) == 0, "conv_clock_probe: 8-byte aligned device words");
+    g_clock_probe = static_cast<unsigned long long*>(probe);
+    return CUTIE_OK;
 }
 
 extern "C" size_t cutie_conv_sync_bytes(int B, int red_tiles, int n_out) {

@@ -590,6 +590,13 @@ __global__ __launch_bounds__(CW_NT) void conv_wide_kernel(ConvParams p) {
         b = bid / p.tiles_h;
     }
     const int h0 = th * TR, w0 = tw * TC, n0 = nt * BN;
+    // clock probe (cutie_conv_clock_probe): the first workgroup's lifetime in shader-clock cycles and in 100 MHz ticks
+    const bool probe = p.clk_probe != nullptr && blockIdx.x == 0;
+    unsigned long long ck0 = 0, rt0 = 0;
+    if (probe) {
+        ck0 = __builtin_amdgcn_s_memtime();
+        rt0 = __builtin_amdgcn_s_memrealtime();
+    }
     float bw_fs = 0.f, bw_fss = 0.f;
     if constexpr (MODE == 1 || MODE == 2) fold_bw_stats<BN>(p, b, n0, bw_fs, bw_fss);
 
@@ -990,6 +997,11 @@ __global__ __launch_bounds__(CW_NT) void conv_wide_kernel(ConvParams p) {
     };
     run(std::false_type{});      // (std::true_type: the staggered schedule of round 2, measured 0.4 % slower, never instantiated)
 
+    if (probe && tid == 0) {      // the K loop is over: cycles and ticks since the workgroup started (its epilogue is not in it)
+        atomicAdd(p.clk_probe, __builtin_amdgcn_s_memtime() - ck0);
+        atomicAdd(p.clk_probe + 1, __builtin_amdgcn_s_memrealtime() - rt0);
+        atomicAdd(p.clk_probe + 2, 1ull);
+    }
     conv_wide_epilogue<DT, BN, MODE, FY, RELU>(p, acc, smem, b, th * p.tiles_w + tw, h0, w0, n0, bw_fs, bw_fss);
 }
 
@@ -1615,6 +1627,7 @@ int launch_conv_wide(const ConvParams& p0, int dtype, int bn, hipStream_t stream
         return CUTIE_E_ARG;
     }
     ConvParams p = p0;
+    p.clk_probe = conv_clock_probe();
     plan_tile_order(p);
     const bool bf = dtype == CUTIE_BF16;
     switch (bn) {

@@ -558,3 +558,11 @@ def convert(src, dst):
     n_rows = src.numel() // C
     call("cutie_convert", ptr(src), ld_of(src), dt_of(src), ptr(dst), ld_of(dst), dt_of(dst), n_rows, C, stream())
     return dst
+
+
+def conv_clock_probe(probe):
+    """Measurement hook (cutie_conv_clock_probe): probe = int64 device tensor of 3 zeroed words, or None to switch it off.
+    While set, workgroup 0 of every wide conv launch adds {shader-clock cycles, 100 MHz ticks, 1} of its K loop to it."""
+    if probe is not None and (probe.dtype != torch.int64 or probe.numel() < 3 or not probe.is_contiguous()):
+        raise CutieError("conv_clock_probe wants a contiguous int64 device tensor of 3 words")
+    call("cutie_conv_clock_probe", ptr(probe))

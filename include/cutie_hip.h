@@ -208,6 +208,12 @@ int cutie_conv_dgrad_in_stats(const cutie_conv_seg* segs /* host */, int n_segs,
  *         launch does not own are left alone (zero the array once when it is allocated), as for `red`.
  * CUTIE_RENDEZVOUS=0 in the environment when the library is loaded selects the two-call form everywhere. */
 size_t cutie_conv_sync_bytes(int B, int red_tiles, int n_out);
+/* Measurement hook, no counterpart in the reference (SURVEY.md 8d asks for the clock the chip actually sustains under the
+ * MFMA kernels, whose peak is quoted at 2.4 GHz).  probe: three 8-byte device words, zeroed by the caller, or NULL to switch
+ * the hook off.  While it is set, workgroup 0 of every launch of the wide conv kernel ADDS {shader-clock cycles, 100 MHz ticks,
+ * 1} of its K loop to them (three atomics per launch): held clock = 100 MHz x cycles / ticks.  Process-wide; set and read it
+ * at synchronisation points. */
+int cutie_conv_clock_probe(void* probe);
 int cutie_conv_dgrad_in_bwd(const cutie_conv_seg* segs /* host */, int n_segs,
                             int B, int H, int W, int n_out,
                             void* dy, int ld_dy,
