@@ -16,9 +16,15 @@ B, H, W, kh, kw = int(os.environ.get("CB_B", 32)), 64, 64, 3, 5
 dev = "cuda:0"
 TDT, CDT = (torch.bfloat16, capi.BF16) if os.environ.get("CB_DTYPE", "f16") == "bf16" else (torch.float16, capi.F16)
 g = torch.Generator().manual_seed(0)
-x = (torch.randn((B, H, W, cin), generator=g)).to(TDT).to(dev)
+x = torch.randn((B, H, W, cin), generator=g)
+if os.environ.get("CB_DATA", "random") == "real":
+    # what a conv of the step reads: a ReLU'd activation, instance-normalised per (sample, channel) - half of the elements of a
+    # plane hold one value (the operands' toggling sets the clock the chip holds)
+    x = torch.relu(x)
+    x = (x - x.mean(dim=(1, 2), keepdim=True)) / x.std(dim=(1, 2), keepdim=True)
+x = x.to(TDT).to(dev)
 dz = (torch.randn((B, H, W, cout), generator=g)).to(TDT).to(dev)
-w = (torch.randn((kh, kw, cin, cout), generator=g) * 0.05).to(dev)
+w = (torch.randn((kh, kw, cin, cout), generator=g) * (0.01 if os.environ.get("CB_DATA", "random") == "real" else 0.05)).to(dev)
 wf, wd = ops.pack_weights(w, CDT)
 out = torch.zeros((B, H, W, cout), dtype=TDT, device=dev)
 bias = torch.zeros(cout, device=dev)
