@@ -14,6 +14,9 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
+# the library's A/B switches (read once at load, include/cutie_hip.h) that take the one-launch forms away on purpose
+_TWO_CALL_BY_SWITCH = any(os.environ.get(k) == "0" for k in ("CUTIE_RENDEZVOUS", "CUTIE_FUSE_NORM_BWD", "CUTIE_CONV_WIDE"))
+
 from oracle import cutie_oracle as co  # noqa: E402
 from oracle import grid_oracle as go  # noqa: E402
 
@@ -472,7 +475,7 @@ def test_conv_in_fwd_one_launch_matches_the_two_call_form(ops, dt, case):
                         torch.zeros((1, T, cout, 2), dtype=torch.float32, device=DEV), sync=s1)
         assert torch.equal(y1[..., :cout], y[B - 1:, :, :, :cout])
     else:
-        assert dt == "f32" or dil == 16 or cout == 36 or H * W > 32 * 256
+        assert _TWO_CALL_BY_SWITCH or dt == "f32" or dil == 16 or cout == 36 or H * W > 32 * 256
     z = co.conv_raw(x.double().cpu(), w.double(), dil) + bias.double()
     ref = co.instance_norm(torch.relu(z))
     assert relerr(y[..., :cout], ref) < {"f32": 1e-4, "f16": 3e-3, "bf16": 2e-2}[dt]
@@ -604,7 +607,7 @@ def test_conv_dgrad_in_bwd_matches_the_two_call_form(ops, dt, case):
         assert bool(((tags == 5) | (tags == 0)).all()) and int((tags == 5).sum()) >= 2 * B * C
         assert dt != "f32" and float(dy.float().abs().max()) == 0.0      # and dy was never written
     else:
-        assert dt == "f32" or case[5] == 16 or case[4] == 36 or case[1] * case[2] > 32 * 256      # only those may take the two-call form
+        assert _TWO_CALL_BY_SWITCH or dt == "f32" or case[5] == 16 or case[4] == 36 or case[1] * case[2] > 32 * 256      # only those may take the two-call form
     # against float64 of the same rounded operands (last iteration)
     a64, d64 = ad[..., :C].double().cpu(), dy_ref[..., :C].double().cpu()
     mean = a64.mean(dim=(1, 2), keepdim=True)

@@ -2,6 +2,7 @@
 kernels it replaces (cutie_l2_add, cutie_sumsq, cutie_adam_step, cutie_pack_weights), and the device-side gate that skips
 a step whose conv launches counted a tile that gave up waiting for its sample's other tiles."""
 import math
+import os
 import types
 
 import numpy as np
@@ -9,6 +10,9 @@ import pytest
 import torch
 
 pytestmark = pytest.mark.gpu
+
+# the library's A/B switches (read once at load) that take the in-launch tile meeting away on purpose: nothing to test then
+_NO_MEETING = any(os.environ.get(k) == "0" for k in ("CUTIE_RENDEZVOUS", "CUTIE_FUSE_NORM_BWD", "CUTIE_CONV_WIDE"))
 
 DEV = "cuda:0"
 V, E, C, H, W, B = 300, 128, 18, 32, 32, 2
@@ -159,6 +163,8 @@ def test_a_late_tile_skips_the_step_on_the_device(where):
     P = eng._plans[(B, H, W, 0)]
     areas = P.sync_fw if where == "forward" else P.sync
     used = [k for k, t in areas.items() if int(t[16:].abs().max()) > 0]      # the areas a one-launch form has written tags into
+    if not used and _NO_MEETING:
+        pytest.skip("the tile meeting is switched off in the environment")
     assert used, "no layer took the one-launch %s form at this shape" % where
     area = areas[used[0]]
     # granules of (sample 0, tile 1): [B][T][n_out] pairs of 8-byte {value, tag}, 64 bytes in; the tag is the high word of
@@ -218,4 +224,6 @@ def test_sync_area_reused_with_another_geometry_is_cleared_by_the_library():
         assert int(late) == 0 and int(sync[0]) == 0
         yy = y.float()
         assert abs(float(yy.mean())) < 1e-2 and abs(float(yy.var(dim=(1, 2), unbiased=False).mean()) - 1.0) < 2e-2
+    if not fused_any and _NO_MEETING:
+        pytest.skip("the tile meeting is switched off in the environment")
     assert fused_any
