@@ -174,7 +174,8 @@ int cutie_conv_in_fwd(const cutie_conv_seg* segs /* host */, int n_segs,
  * CUTIE_RENDEZVOUS, each "0" to turn the named path off, and CUTIE_CONV_DUO (0: no 4-wave conv kernel, 1 = default:
  * for 128-channel tiles and short 64-channel 1x1 launches, 2: for the 256-channel layers too) - once at load, never
  * per call; none of them changes results beyond the rounding differences documented at the entry points;
- * CUTIE_CONV_RING is read too but selects nothing outside a -DCW_WITH_RING variant build). */
+ * CUTIE_CONV_RING and CUTIE_CONV_PATCH are read too but select nothing outside -DCW_WITH_RING / -DCW_WITH_PATCH variant
+ * builds). */
 int cutie_conv_dgrad_in_stats(const cutie_conv_seg* segs /* host */, int n_segs,
                               int B, int H, int W, int n_out,
                               void* out, int ld_out, int out_dtype,
