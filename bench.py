@@ -143,6 +143,9 @@ def sample_clock(ops, dev, step, fence, steps=8):
     launch of `steps` extra, untimed steps adds its K loop's shader-clock cycles (s_memtime) and 100 MHz ticks
     (s_memrealtime) to a probe buffer (cutie_conv_clock_probe)."""
     probe = torch.zeros(3, dtype=torch.int64, device=dev)
+    for _ in range(6):      # the device may have idled behind the timed region (CPU baseline): back to the steady state first
+        step()
+    fence()
     ops.conv_clock_probe(probe)
     try:
         for _ in range(steps):
@@ -428,18 +431,20 @@ def main():
             out["roofline_hbm"], _ = calls.report(B * H * W, E, C)
             if args.launch_table:
                 print("\n".join(timer.launch_table(peak)), file=sys.stderr, flush=True)
-        if not args.no_clock:
-            # the peak is the vendor's 2.4 GHz figure - print the shader clock the chip actually HOLDS under
-            # this step - measured inside the conv kernels themselves on extra, untimed steps behind the timed region (amdsmi's
-            # "current clock" read 1147, 1613 and 2250 MHz for the same step on three boxes: a DPM level, not the clock).
-            clk = sample_clock(ops, dev, step, fence)
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(C, V, E, H, W, packed)
+    if not args.no_clock:
+        # the peak is the vendor's 2.4 GHz figure - print the shader clock the chip actually HOLDS under this
+        # step, measured inside the conv kernels themselves on extra, untimed steps behind the timed region (amdsmi's "current
+        # clock" read 1147, 1613 and 2250 MHz for the same step on three boxes: a DPM level, not the clock).  EVERY rank runs
+        # the extra steps (under data parallelism a step holds collectives); rank 0 reports its own GPU's figure.
+        clk = sample_clock(ops, dev, step, fence)
+        if rank == 0:
             out["config"]["sclk_under_load"] = clk
             if clk.get("mhz"):
                 # the same whole-step fraction against the MFMA rate at the clock the chip holds (peak x held / 2400 MHz)
                 out["config"]["whole_step_mfma_frac_at_held_clock"] = round(
                     out["config"]["whole_step_mfma_frac"] * clk["mhz_nominal"] / clk["mhz"], 4)
-        if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(C, V, E, H, W, packed)
     if args.dtype in ("f16", "bf16") and not args.no_alt:
         # the same step on the other 16-bit element type (same tiles, same MFMA rate): bf16 beside the f16
         # headline.  bf16's 8 significant bits put it outside the 2e-2 logit tolerance (tests/test_model_gpu.py),
